@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the per-pixel sampling hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one frame of synthetic input: every pixel x every sample of the workload is
+generated, traced, shaded and accumulated on the GPU (one launch per rank), the per-rank tile shards are gathered
+to rank 0 over RCCL (N > 1) and scattered into the image-major framebuffer.  Scene (BVH) and camera are resident in
+HBM before the timed region; the framebuffer stays in HBM.
+
+Workload at N = 1 (BASELINE.json configs[1]): teapot.obj, 1920x1080, 256 spp, tile 64, seed 0x5EED, teapot view of
+benches/render_teapot.rs:12-19, reference semantics (primary ray + |d.n| shading = depth 1; the reference has no
+bounce loop).  A "ray" is one Object::intersect call, so rays == samples here.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run): tiles are sharded round-robin over the ranks, the total
+work is fixed ("strong" scaling), no collective on the data path except the final framebuffer gather.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_RAY_DEPTH1 = 136  # algorithmic HBM bytes per ray segment of the depth-1 wavefront formulation
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "teapot.obj"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-tile-stride", type=int, default=16, help="cpu_baseline renders every k-th tile")
+    ap.add_argument("--check", action="store_true", help="compare a few tiles of the GPU frame with the oracle")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """The oracle (C restatement of the reference CPU path: one thread per core, atomic tile queue,
+    machinery.rs:31-116) timed on this box's host cores on a bounded sample of the SAME workload."""
+    from oracle import pyoracle as po
+
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    b = po.Bvh.from_obj(args.scene)
+    s = po.build_sampler(po.teapot_camera(), args.width, args.height)
+    ntiles = len(po.tile_ordering(0, 0, args.width, args.height, args.tile))
+    stride = max(1, args.cpu_tile_stride)
+    _, _, secs, rays, _ = b.render_image_mt(s, args.width, args.height, args.spp, args.seed, args.tile, cores, 0, stride)
+    return {
+        "value": rays / secs / 1e6,
+        "unit": "Mrays/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"every {stride}th of the {ntiles} 64x64 tiles of the same frame at full {args.spp} spp "
+                  f"({rays / 1e6:.1f} Mrays, {secs:.1f} s wall on {cores} threads); C restatement of the reference CPU path, "
+                  "not the Rust reference (no Rust toolchain in this pipeline)",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import minipath_amd as mp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ctx = mp.Context(local_rank)
+    scene = mp.Scene(mp.TriangleBvh.with_obj(args.scene, ctx))
+    cam = mp.Camera.teapot_view()
+    st = mp.RenderSettings(args.tile, args.spp, (args.width, args.height), seed=args.seed)
+    all_tiles = mp.tile_ordering(mp.ScreenBlock(0, 0, args.width, args.height), args.tile)
+    my_tiles = all_tiles[rank::world]
+    fr = mp.FrameRenderer(scene, cam, st, tiles=my_tiles)
+    per_rank = (len(all_tiles) + world - 1) // world
+    ts = args.tile
+    # equal-size shards for the gather; rank-major tile list for the un-tile on rank 0
+    shard = torch.zeros((per_rank, ts, ts, 4), dtype=torch.float32, device=dev)
+    gathered = [torch.zeros_like(shard) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gather_tiles = []
+    for r in range(world):
+        tl = all_tiles[r::world]
+        gather_tiles += tl + [mp.ScreenBlock(0, 0, 0, 0)] * (per_rank - len(tl))
+    full_fr = mp.FrameRenderer(scene, cam, st, tiles=all_tiles[:1]) if rank == 0 else None  # untile helper only
+    total_rays = args.width * args.height * args.spp
+    kernel_ms = []
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def step(timed):
+        ev0.record()
+        buf = fr.render()
+        ev1.record()
+        img = None
+        if world > 1:
+            shard[: len(my_tiles)].copy_(buf[: len(my_tiles)])
+            dist.gather(shard, gathered, dst=0)
+            if rank == 0:
+                img, _ = untile_gathered()
+        else:
+            img, _ = fr.untile(want_u8=True)
+        if timed:
+            torch.cuda.synchronize(dev)
+            kernel_ms.append(ev0.elapsed_time(ev1))
+        return img
+
+    def untile_gathered():
+        cat = torch.cat(gathered, 0)
+        keep = [i for i, t in enumerate(gather_tiles) if not t.is_empty()]
+        tiles = [gather_tiles[i] for i in keep]
+        if len(keep) != len(gather_tiles):
+            cat = cat[torch.tensor(keep, device=dev)]
+        return full_fr.untile(cat.contiguous(), tiles, want_u8=True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    img = None
+    for _ in range(args.steps):
+        img = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        kmax = torch.tensor([sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+        k_ms = float(kmax.item())
+    else:
+        k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_rays * args.steps / elapsed / 1e6
+        # dominant kernel: render_tiles_kernel.  Algorithmic bytes per launch = B_ray x rays of this rank's launch
+        # (DESIGN.md "Roofline"); duration from HIP events on the launch stream.
+        rays_per_launch = fr.rays_per_frame
+        achieved = rays_per_launch * B_RAY_DEPTH1 / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s",
+            "value": value,
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "samples_per_s": total_rays * args.steps / elapsed,
+            "config": {
+                "workload": f"{os.path.basename(args.scene)} {args.width}x{args.height} {args.spp}spp tile{args.tile} "
+                            f"seed{args.seed:#x} depth1 (reference semantics: primary ray + |d.n|, worker.rs:51-66)",
+                "rays_per_step": total_rays,
+                "parallelism": f"tiles round-robin over {world} rank(s)" + (" + RCCL gather to rank 0" if world > 1 else ""),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "render_tiles_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel_ms": k_ms,
+                "algorithmic_bytes_per_launch": rays_per_launch * B_RAY_DEPTH1,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        if args.check and img is not None:
+            from oracle import pyoracle as po
+            import numpy as np
+
+            ob = po.Bvh.from_obj(args.scene)
+            s = po.build_sampler(po.teapot_camera(), args.width, args.height)
+            host = img.cpu().numpy()
+            bad = 0
+            for t in all_tiles[:: max(1, len(all_tiles) // 6)]:
+                f, _ = ob.render_tile(s, args.width, args.height, min(args.spp, 256), args.seed, t.min_x, t.min_y, t.max_x, t.max_y)
+                bad += int(np.sum(host[t.min_y:t.max_y, t.min_x:t.max_x].view(np.uint32) != f.view(np.uint32)))
+            out["check_mismatches"] = bad
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

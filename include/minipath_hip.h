@@ -1,0 +1,198 @@
+/*
+ * minipath_hip.h -- C ABI of the MI355X (gfx950) implementation of minipath's per-pixel sampling hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI; its seam is the Rust API of
+ * src/renderer (+ src/screen_block.rs, src/camera.rs, src/scene/triangle_bvh).  Every entry point below names
+ * the reference interface it replaces (file:line in the reference checkout).  A Rust `src/renderer`-shaped shim
+ * binds exactly these symbols (INTEGRATION.md shows it).
+ *
+ * Conventions
+ *   - plain C types, pointers and sizes only; no C++/torch types cross the boundary;
+ *   - every function returns an int status (MP_OK == 0); no exception or abort crosses the ABI; the message of
+ *     the last failure on the calling thread is mp_last_error();
+ *   - "d_" pointers are device (HBM) pointers on the context's GPU, everything else is host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - one context drives ONE GPU.  Multi-GPU is one process (and one context) per GPU, tiles sharded across
+ *     ranks by the caller, framebuffer gathered with RCCL by the caller (bench.py / minipath_amd.distributed).
+ *
+ * Seeded mode.  The reference seeds every worker's RNG from the OS (worker.rs:25), so it has no reproducible
+ * sample stream.  This library defines one: sample s of pixel (x,y) uses
+ *   Xoshiro256++::seed_from_u64(seed + ((y*W + x)*spp + s))
+ * followed by the draw order of CameraSampler::sample_ray (camera.rs:176-191).
+ */
+#ifndef MINIPATH_HIP_H
+#define MINIPATH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_OK 0
+#define MP_ERR_INVALID 1      /* bad argument */
+#define MP_ERR_IO 2           /* ObjOpenError::ReadError / ParseError, building.rs:209-216 */
+#define MP_ERR_BUILD 3        /* a condition on which the reference builder panics (building.rs:178,275) */
+#define MP_ERR_HIP 4          /* HIP runtime error */
+#define MP_ERR_UNSUPPORTED 5
+#define MP_ERR_ABORTED 6
+
+#define MP_NO_PRIM 0xFFFFFFFFu /* TriangleIdx::default() (usize::MAX) narrowed to u32, triangle_bvh/mod.rs:143-147 */
+#define MP_LINK_NULL 0xFFFFFFF8u /* CompressedNodeLink::NULL, triangle_bvh/mod.rs:63 */
+
+typedef struct mp_ctx mp_ctx;
+typedef struct mp_scene mp_scene;
+typedef struct mp_render mp_render;
+
+/* geometry/mod.rs:15 ScreenBlock = AABB<Point2<u32>> : [min, max) */
+typedef struct { uint32_t min_x, min_y, max_x, max_y; } mp_block;
+
+/* camera.rs:9-18 Camera.  camera_to_world (Isometry3<f32>) = unit quaternion (i,j,k,w) + translation. */
+typedef struct {
+    float q[4];
+    float t[3];
+    float focus_distance;
+    int32_t sensor_is_width; /* camera.rs:20-24 SensorSize::Width(1) / ::Height(0) */
+    float sensor_size;
+    float focal_length;
+    float f_number;
+} mp_camera;
+
+/* camera.rs:26-39 CameraSampler: the 15 floats, in declaration order. */
+typedef struct {
+    float center[3];
+    float up[3];
+    float right[3];
+    float film_origin_offset[3];
+    float pixel_scale;
+    float lens_radius;
+    float lens_weight;
+} mp_camera_sampler;
+
+/* renderer/mod.rs:7-13 RenderSettings, plus the build-defined seed (see "Seeded mode"). */
+typedef struct {
+    uint32_t tile_size;    /* NonZeroU32 */
+    uint32_t sample_count; /* NonZeroU32 */
+    uint32_t width, height;
+    uint64_t seed;
+    uint32_t flags;        /* MP_FLAG_* */
+    uint32_t reserved;
+} mp_settings;
+
+#define MP_FLAG_SHUFFLE_TILES 1u /* centre-out tile order with random noise (screen_block.rs:74-78); default: row-major */
+
+/* machinery.rs:180-189 RenderProgressSnapshot */
+typedef struct { size_t finished, total; } mp_progress;
+
+/* triangle_bvh/mod.rs:20-30 TriangleBvh, as counts */
+typedef struct {
+    uint32_t root_link;
+    uint32_t inner_count;    /* InnerNode, 128 B each in the reference layout */
+    uint32_t packet_count;   /* RelativeTriangle8, 144 B each */
+    uint32_t vertex_count;
+    uint32_t triangle_count; /* real (unpadded) triangles */
+    uint32_t depth;          /* max inner nodes on a root-to-leaf path; traversal stack <= 7*depth+1 */
+    float bbox_min[3], bbox_max[3];
+    uint64_t device_bytes;
+} mp_scene_info;
+
+/* geometry/mod.rs:71-80 HitRecord, batched SoA on the device (any pointer may be NULL to skip that output) */
+typedef struct {
+    float *d_t;             /* f32::MAX on miss (ray_bvh_intersection.rs:35) */
+    uint32_t *d_prim;       /* packet*8+lane, MP_NO_PRIM on miss */
+    float *d_u, *d_v;       /* LeafHitRecord.uv */
+    float *d_point;         /* n*3, HitRecord.point   (optional) */
+    float *d_normal;        /* n*3, HitRecord.normal  (optional) */
+    float *d_tex;           /* n*3, HitRecord.texture_coords (optional) */
+} mp_hits_soa;
+
+typedef void (*mp_tile_started_cb)(void *user, mp_block tile);                       /* F1, machinery.rs:22 */
+typedef void (*mp_tile_finished_cb)(void *user, mp_block tile, mp_progress snapshot); /* F2, machinery.rs:23 */
+
+const char *mp_last_error(void);
+const char *mp_version(void);
+
+/* ---- context ---------------------------------------------------------------------------------------- */
+int mp_ctx_create(int device_id, mp_ctx **out);
+void mp_ctx_destroy(mp_ctx *ctx);
+int mp_ctx_device(const mp_ctx *ctx, int *device_id, int *cu_count);
+
+/* ---- camera.rs ------------------------------------------------------------------------------------------ */
+int mp_camera_default(mp_camera *cam);                                                            /* :42-52 */
+int mp_camera_look_at(mp_camera *cam, const float eye[3], const float at[3], const float up[3]);   /* :93-101 */
+int mp_camera_look_direction(mp_camera *cam, const float eye[3], const float fwd[3], const float up[3]); /* :104-116 */
+int mp_camera_translate(mp_camera *cam, const float t[3]);                                        /* :119-121 */
+int mp_camera_basis(const mp_camera *cam, float center[3], float fwd[3], float up[3], float right[3]); /* :148-171 */
+int mp_camera_build_sampler(const mp_camera *cam, uint32_t width, uint32_t height, mp_camera_sampler *out); /* :123-146 */
+
+/* ---- screen_block.rs ------------------------------------------------------------------------------------ */
+/* ScreenBlock::tile_ordering :46-81.  out==NULL returns the count in *n.  shuffle_seed 0 = row-major grid. */
+int mp_tile_ordering(mp_block block, uint32_t tile_size, uint64_t shuffle_seed, mp_block *out, size_t cap, size_t *n);
+
+/* ---- scene/triangle_bvh ---------------------------------------------------------------------------------- */
+/* TriangleBvh::with_obj building.rs:28-34 : load + dedupe + build + upload to HBM.
+ * ctx may be NULL: the scene is then host-only (mp_scene_info_get / mp_scene_export work, rendering does not). */
+int mp_scene_from_obj(mp_ctx *ctx, const char *path, mp_scene **out);
+/* TriangleBvh::build building.rs:83-107 over caller-supplied indexed triangles (arrays are copied).
+ * normals/tex may be NULL (=> zero normals => flat shading, building.rs:200). */
+int mp_scene_from_triangles(mp_ctx *ctx, const float *positions, const float *normals, const float *tex,
+                            uint32_t vertex_count, const uint32_t *indices, uint32_t triangle_count, mp_scene **out);
+void mp_scene_destroy(mp_scene *scene);
+int mp_scene_info_get(const mp_scene *scene, mp_scene_info *out);
+/* Export of the reference-layout arrays (for parity checks and for a Rust caller that wants to rebuild a
+ * TriangleBvh): inner nodes 128 B (6 x u16[8] min.xyz,max.xyz + 8 x u32 links), packets 144 B (3 verts x 3
+ * coords x u16[8]), tri shading 16 B (3 x u32 vertex index + u32 flat), vertex normals / tex (n*3 f32).
+ * Any pointer may be NULL. */
+int mp_scene_export(const mp_scene *scene, void *inner_nodes, void *packets, void *tri_shading, float *vertex_normals,
+                    float *vertex_tex);
+
+/* ---- impl Object for TriangleBvh :: intersect, batched (ray_bvh_intersection.rs:26-96) -------------------- */
+/* d_o/d_d: SoA device arrays of n floats each (ox,oy,oz / dx,dy,dz).  Directions need not be unit: Ray::new
+ * (geometry/mod.rs:45-54) is applied on the device. */
+int mp_trace_rays(mp_ctx *ctx, const mp_scene *scene, const float *d_ox, const float *d_oy, const float *d_oz,
+                  const float *d_dx, const float *d_dy, const float *d_dz, uint64_t n, const mp_hits_soa *hits,
+                  void *stream);
+/* CameraSampler::sample_ray (camera.rs:176-191) batched, seeded mode: writes unit-direction rays for sample s of
+ * every pixel of `block` (x fastest) -- the ray stream of the staged (wavefront) pipeline. */
+int mp_generate_rays(mp_ctx *ctx, const mp_camera_sampler *sampler, const mp_settings *settings, mp_block block,
+                     uint32_t sample, float *d_ox, float *d_oy, float *d_oz, float *d_dx, float *d_dy, float *d_dz,
+                     void *stream);
+
+/* ---- Worker::render_tile (worker.rs:32-49) ---------------------------------------------------------------- */
+/* Synchronous, host output.  rgba_f32 = w*h*4 pre-quantisation means (worker.rs:44), x fastest; rgba_u8 =
+ * color_to_image (worker.rs:69-76).  Either may be NULL. */
+int mp_render_tile(mp_ctx *ctx, const mp_scene *scene, const mp_camera_sampler *sampler, const mp_settings *settings,
+                   mp_block tile, float *rgba_f32, uint8_t *rgba_u8);
+/* Device output, asynchronous on `stream`: renders `n_tiles` tiles in ONE launch.  Tile i's pixels go to
+ * d_rgba_f32 + i*tile_size*tile_size*4 (tile-major, row stride = tile_size, clipped tiles leave the rest
+ * untouched).  This is the bench hot path and the per-rank shard of the multi-GPU render. */
+int mp_render_tiles_device(mp_ctx *ctx, const mp_scene *scene, const mp_camera_sampler *sampler,
+                           const mp_settings *settings, const mp_block *tiles, size_t n_tiles, float *d_rgba_f32,
+                           void *stream);
+/* machinery.rs:78-89 (tile buffer -> image copy) on the device: scatters tile-major tiles into an image-major
+ * f32 frame and/or its color_to_image u8 frame (either may be NULL). */
+int mp_untile(mp_ctx *ctx, const mp_settings *settings, const mp_block *tiles, size_t n_tiles,
+              const float *d_tiles_f32, float *d_image_f32, uint8_t *d_image_u8, void *stream);
+/* Rays traced (Object::intersect calls) and their wall time inside the last mp_render_tiles_device launch is
+ * NOT measured here: the caller brackets the stream with events. */
+
+/* ---- render() / RenderProgress (machinery.rs:20-178) ------------------------------------------------------ */
+/* Asynchronous like render(): returns after starting a library-owned host thread that walks the tile ordering,
+ * launching batches of tiles on the GPU; callbacks (may be NULL) are invoked from that thread once per tile
+ * start and once per tile end. */
+int mp_render_begin(mp_ctx *ctx, const mp_scene *scene, const mp_camera *camera, const mp_settings *settings,
+                    mp_tile_started_cb started, mp_tile_finished_cb finished, void *user, mp_render **out);
+int mp_render_progress(const mp_render *r, mp_progress *out);        /* RenderProgress::progress :133-142 */
+int mp_render_is_finished(const mp_render *r, int *finished);        /* ::is_finished :144-146 */
+int mp_render_elapsed_ns(const mp_render *r, uint64_t *ns);          /* ::elapsed :150-157 */
+int mp_render_abort(mp_render *r);                                   /* ::abort :161-165 */
+int mp_render_wait(mp_render *r);                                    /* ::wait :169-173 ; returns the worker's status */
+int mp_render_image_u8(mp_render *r, uint8_t *dst /* w*h*4 */);      /* ::image :175 (copy under the lock) */
+int mp_render_image_f32(mp_render *r, float *dst /* w*h*4 */);       /* pre-quantisation means (worker.rs:44) */
+void mp_render_destroy(mp_render *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

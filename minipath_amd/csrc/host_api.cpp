@@ -1,0 +1,639 @@
+// C ABI (include/minipath_hip.h): context, scene upload, synchronous tile rendering and the asynchronous
+// render()/RenderProgress machinery (reference: src/renderer/machinery.rs).
+#include <hip/hip_runtime_api.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "mp_internal.h"
+
+namespace mp {
+
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+
+namespace {
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) { return fail(MP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+
+#define MP_HIP(call)                                  \
+    do {                                              \
+        hipError_t e_ = (call);                       \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+constexpr float kInvU16Max = 1.0f / 65535.0f;
+inline float dequantise(uint16_t q, float size, float mn) {  // compressed_geometry.rs:48-51,95-110
+    return std::fmaf(size, static_cast<float>(static_cast<int32_t>(q)) * kInvU16Max, mn);
+}
+
+// worker.rs:69-76 on the host (used by the synchronous / async host-image paths)
+inline uint8_t to_u8(float c) {
+    float x = std::round(c * 255.0f);
+    if (x != x) return 0;
+    x = x < 0.0f ? 0.0f : (x > 255.0f ? 255.0f : x);
+    return static_cast<uint8_t>(x);
+}
+
+}  // namespace
+}  // namespace mp
+
+using namespace mp;
+
+struct mp_ctx {
+    int device = 0;
+    int cu_count = 0;
+    // work-queue heads: one per launch, handed out round-robin so that launches on different streams never share one
+    static constexpr uint32_t kCounters = 256;
+    uint32_t* d_counters = nullptr;
+    std::atomic<uint32_t> next_counter{0};
+    uint32_t* take_counter() { return d_counters + (next_counter.fetch_add(1, std::memory_order_relaxed) % kCounters); }
+};
+
+struct mp_scene {
+    mp_ctx* ctx = nullptr;
+    HostBvh host;
+    DevScene dev;
+    void* d_nodes = nullptr;
+    void* d_tris = nullptr;
+    void* d_shade = nullptr;
+    void* d_vidx = nullptr;
+    void* d_vtex = nullptr;
+    uint64_t device_bytes = 0;
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int upload_scene(mp_scene* s) {
+    const HostBvh& h = s->host;
+    const size_t ni = h.inner.size(), np = h.packets.size();
+    std::vector<float> nodes(std::max<size_t>(ni, 1) * kNodeDwords, 0.0f);
+    for (size_t n = 0; n < ni; n++) {
+        const InnerNodeRef& nd = h.inner[n];
+        const Box3& e = h.inner_box[n];
+        float size[3] = {e.mx[0] - e.mn[0], e.mx[1] - e.mn[1], e.mx[2] - e.mn[2]};
+        float* o = &nodes[n * kNodeDwords];
+        for (int i = 0; i < 8; i++) {
+            for (int k = 0; k < 3; k++) {
+                o[k * 8 + i] = dequantise(nd.bmin[k][i], size[k], e.mn[k]);        // ray_bvh_intersection.rs:155
+                o[(3 + k) * 8 + i] = dequantise(nd.bmax[k][i], size[k], e.mn[k]);
+            }
+            std::memcpy(&o[48 + i], &nd.link[i], 4);
+        }
+    }
+    std::vector<float> tris(np * kPacketDwords, 0.0f);
+    std::vector<float> shade(np * 8 * 12, 0.0f);
+    std::vector<uint32_t> vidx(np * 8 * 3, 0);
+    for (size_t p = 0; p < np; p++) {
+        const TriPacketRef& pk = h.packets[p];
+        const Box3& e = h.packet_box[p];
+        float size[3] = {e.mx[0] - e.mn[0], e.mx[1] - e.mn[1], e.mx[2] - e.mn[2]};
+        float* o = &tris[p * kPacketDwords];
+        for (int i = 0; i < 8; i++) {
+            float v[3][3];
+            for (int a = 0; a < 3; a++)
+                for (int k = 0; k < 3; k++) v[a][k] = dequantise(pk.v[a][k][i], size[k], e.mn[k]);  // :160-162
+            for (int k = 0; k < 3; k++) {
+                o[k * 8 + i] = v[0][k];
+                o[(3 + k) * 8 + i] = v[1][k] - v[0][k];  // e1, triangle.rs:195
+                o[(6 + k) * 8 + i] = v[2][k] - v[0][k];  // e2, triangle.rs:196
+            }
+            const TriShadingRef& sh = h.shading[p * 8 + i];
+            float* so = &shade[(p * 8 + i) * 12];
+            for (int a = 0; a < 3; a++) {
+                for (int k = 0; k < 3; k++) so[a * 3 + k] = h.vnormal[3 * static_cast<size_t>(sh.vi[a]) + k];
+                vidx[(p * 8 + i) * 3 + a] = sh.vi[a];
+            }
+            uint32_t flat = sh.flat;
+            std::memcpy(&so[9], &flat, 4);
+        }
+    }
+    auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+        bytes = std::max<size_t>(bytes, 16);
+        MP_HIP(hipMalloc(dst, bytes));
+        MP_HIP(hipMemset(*dst, 0, bytes));
+        s->device_bytes += bytes;
+        return MP_OK;
+    };
+    int rc;
+    if ((rc = up(&s->d_nodes, nodes.data(), nodes.size() * 4))) return rc;
+    if ((rc = up(&s->d_tris, tris.data(), tris.size() * 4))) return rc;
+    if ((rc = up(&s->d_shade, shade.data(), shade.size() * 4))) return rc;
+    if ((rc = up(&s->d_vidx, vidx.data(), vidx.size() * 4))) return rc;
+    if ((rc = up(&s->d_vtex, h.vtex.data(), h.vtex.size() * 4))) return rc;
+    MP_HIP(hipMemcpy(s->d_nodes, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice));
+    if (!tris.empty()) MP_HIP(hipMemcpy(s->d_tris, tris.data(), tris.size() * 4, hipMemcpyHostToDevice));
+    if (!shade.empty()) MP_HIP(hipMemcpy(s->d_shade, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
+    if (!vidx.empty()) MP_HIP(hipMemcpy(s->d_vidx, vidx.data(), vidx.size() * 4, hipMemcpyHostToDevice));
+    if (!h.vtex.empty()) MP_HIP(hipMemcpy(s->d_vtex, h.vtex.data(), h.vtex.size() * 4, hipMemcpyHostToDevice));
+    s->dev.nodes = static_cast<const float*>(s->d_nodes);
+    s->dev.tris = static_cast<const float*>(s->d_tris);
+    s->dev.shade = static_cast<const float*>(s->d_shade);
+    s->dev.vidx = static_cast<const uint32_t*>(s->d_vidx);
+    s->dev.vtex = static_cast<const float*>(s->d_vtex);
+    s->dev.root = h.root;
+    s->dev.inner_count = static_cast<uint32_t>(ni);
+    s->dev.packet_count = static_cast<uint32_t>(np);
+    s->dev.stack_cap = 7 * h.depth + 1;
+    return MP_OK;
+}
+
+int finish_scene(mp_ctx* ctx, std::unique_ptr<mp_scene> s, mp_scene** out) {
+    s->ctx = ctx;
+    if (!ctx) {  // host-only scene: build + export work, nothing is uploaded and nothing can be rendered
+        *out = s.release();
+        return MP_OK;
+    }
+    DeviceGuard g(ctx->device);
+    if (!g.ok) return fail(MP_ERR_HIP, "hipSetDevice failed");
+    int rc = upload_scene(s.get());
+    if (rc) {
+        mp_scene_destroy(s.release());
+        return rc;
+    }
+    *out = s.release();
+    return MP_OK;
+}
+
+bool valid_settings(const mp_settings* st) {
+    return st && st->tile_size > 0 && st->sample_count > 0 && st->width > 0 && st->height > 0;
+}
+
+// Renders `tiles` into a tile-major device buffer (launch only).
+int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler& sampler, const mp_settings& st,
+                        const mp_block* d_tiles, size_t n, float* d_out, void* stream) {
+    RenderLaunch L;
+    L.scene = scene->dev;
+    L.sampler = sampler;
+    L.width = st.width;
+    L.height = st.height;
+    L.spp = st.sample_count;
+    L.tile_size = st.tile_size;
+    L.seed = st.seed;
+    L.d_tiles = d_tiles;
+    L.n_tiles = static_cast<uint32_t>(n);
+    L.d_out = d_out;
+    L.d_counter = ctx->take_counter();
+    L.cu_count = ctx->cu_count;
+    std::string err;
+    int rc = launch_render_tiles(L, stream, err);
+    if (rc) return fail(rc, err);
+    return MP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mp_last_error(void) { return g_last_error.c_str(); }
+const char* mp_version(void) { return "minipath_hip 0.1 (gfx950)"; }
+
+int mp_ctx_create(int device_id, mp_ctx** out) {
+    if (!out) return fail(MP_ERR_INVALID, "out is NULL");
+    int count = 0;
+    MP_HIP(hipGetDeviceCount(&count));
+    if (device_id < 0 || device_id >= count) return fail(MP_ERR_INVALID, "device_id out of range");
+    DeviceGuard g(device_id);
+    if (!g.ok) return fail(MP_ERR_HIP, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    MP_HIP(hipGetDeviceProperties(&prop, device_id));
+    auto ctx = std::make_unique<mp_ctx>();
+    ctx->device = device_id;
+    ctx->cu_count = prop.multiProcessorCount;
+    MP_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), mp_ctx::kCounters * sizeof(uint32_t)));
+    MP_HIP(hipMemset(ctx->d_counters, 0, mp_ctx::kCounters * sizeof(uint32_t)));
+    *out = ctx.release();
+    return MP_OK;
+}
+
+void mp_ctx_destroy(mp_ctx* ctx) {
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    delete ctx;
+}
+
+int mp_ctx_device(const mp_ctx* ctx, int* device_id, int* cu_count) {
+    if (!ctx) return fail(MP_ERR_INVALID, "ctx is NULL");
+    if (device_id) *device_id = ctx->device;
+    if (cu_count) *cu_count = ctx->cu_count;
+    return MP_OK;
+}
+
+// ---- camera ---------------------------------------------------------------------------------------------------
+int mp_camera_default(mp_camera* cam) {
+    if (!cam) return fail(MP_ERR_INVALID, "cam is NULL");
+    camera_default(*cam);
+    return MP_OK;
+}
+int mp_camera_look_at(mp_camera* cam, const float eye[3], const float at[3], const float up[3]) {
+    if (!cam || !eye || !at || !up) return fail(MP_ERR_INVALID, "NULL argument");
+    camera_look_at(*cam, eye, at, up);
+    return MP_OK;
+}
+int mp_camera_look_direction(mp_camera* cam, const float eye[3], const float fwd[3], const float up[3]) {
+    if (!cam || !eye || !fwd || !up) return fail(MP_ERR_INVALID, "NULL argument");
+    camera_look_direction(*cam, eye, fwd, up);
+    return MP_OK;
+}
+int mp_camera_translate(mp_camera* cam, const float t[3]) {
+    if (!cam || !t) return fail(MP_ERR_INVALID, "NULL argument");
+    for (int k = 0; k < 3; k++) cam->t[k] = t[k] + cam->t[k];  // (Translation3 * Isometry3).translation
+    return MP_OK;
+}
+int mp_camera_basis(const mp_camera* cam, float center[3], float fwd[3], float up[3], float right[3]) {
+    if (!cam || !center || !fwd || !up || !right) return fail(MP_ERR_INVALID, "NULL argument");
+    camera_basis(*cam, center, fwd, up, right);
+    return MP_OK;
+}
+int mp_camera_build_sampler(const mp_camera* cam, uint32_t width, uint32_t height, mp_camera_sampler* out) {
+    if (!cam || !out) return fail(MP_ERR_INVALID, "NULL argument");
+    if (width == 0 || height == 0) return fail(MP_ERR_INVALID, "empty resolution");
+    camera_build_sampler(*cam, width, height, *out);
+    return MP_OK;
+}
+
+int mp_tile_ordering(mp_block block, uint32_t tile_size, uint64_t shuffle_seed, mp_block* out, size_t cap, size_t* n) {
+    if (tile_size == 0) return fail(MP_ERR_INVALID, "tile_size must be non-zero (NonZeroU32)");
+    if (!n) return fail(MP_ERR_INVALID, "n is NULL");
+    std::vector<mp_block> t = tile_ordering(block, tile_size, shuffle_seed);
+    *n = t.size();
+    if (out) std::memcpy(out, t.data(), std::min(cap, t.size()) * sizeof(mp_block));
+    return MP_OK;
+}
+
+// ---- scene ----------------------------------------------------------------------------------------------------
+int mp_scene_from_obj(mp_ctx* ctx, const char* path, mp_scene** out) {
+    if (!path || !out) return fail(MP_ERR_INVALID, "NULL argument");
+    std::vector<float> pos, nrm, tex;
+    std::vector<uint32_t> tri;
+    std::string err;
+    int rc = load_obj(path, pos, nrm, tex, tri, err);
+    if (rc) return fail(rc, err);
+    auto s = std::make_unique<mp_scene>();
+    rc = build_bvh(pos.data(), nrm.data(), tex.data(), static_cast<uint32_t>(pos.size() / 3), tri.data(),
+                   static_cast<uint32_t>(tri.size() / 3), s->host, err);
+    if (rc) return fail(rc, err);
+    return finish_scene(ctx, std::move(s), out);
+}
+
+int mp_scene_from_triangles(mp_ctx* ctx, const float* positions, const float* normals, const float* tex,
+                            uint32_t vertex_count, const uint32_t* indices, uint32_t triangle_count, mp_scene** out) {
+    if (!positions || !indices || !out) return fail(MP_ERR_INVALID, "NULL argument");
+    auto s = std::make_unique<mp_scene>();
+    std::string err;
+    int rc = build_bvh(positions, normals, tex, vertex_count, indices, triangle_count, s->host, err);
+    if (rc) return fail(rc, err);
+    return finish_scene(ctx, std::move(s), out);
+}
+
+void mp_scene_destroy(mp_scene* s) {
+    if (!s) return;
+    if (s->ctx) {
+        DeviceGuard g(s->ctx->device);
+        for (void* p : {s->d_nodes, s->d_tris, s->d_shade, s->d_vidx, s->d_vtex})
+            if (p) (void)hipFree(p);
+    }
+    delete s;
+}
+
+int mp_scene_info_get(const mp_scene* s, mp_scene_info* out) {
+    if (!s || !out) return fail(MP_ERR_INVALID, "NULL argument");
+    out->root_link = s->host.root;
+    out->inner_count = static_cast<uint32_t>(s->host.inner.size());
+    out->packet_count = static_cast<uint32_t>(s->host.packets.size());
+    out->vertex_count = s->host.vertex_count;
+    out->triangle_count = s->host.triangle_count;
+    out->depth = s->host.depth;
+    for (int k = 0; k < 3; k++) {
+        out->bbox_min[k] = s->host.bbox.mn[k];
+        out->bbox_max[k] = s->host.bbox.mx[k];
+    }
+    out->device_bytes = s->device_bytes;
+    return MP_OK;
+}
+
+int mp_scene_export(const mp_scene* s, void* inner_nodes, void* packets, void* tri_shading, float* vertex_normals,
+                    float* vertex_tex) {
+    if (!s) return fail(MP_ERR_INVALID, "scene is NULL");
+    const HostBvh& h = s->host;
+    if (inner_nodes && !h.inner.empty()) std::memcpy(inner_nodes, h.inner.data(), h.inner.size() * sizeof(InnerNodeRef));
+    if (packets && !h.packets.empty()) std::memcpy(packets, h.packets.data(), h.packets.size() * sizeof(TriPacketRef));
+    if (tri_shading && !h.shading.empty()) std::memcpy(tri_shading, h.shading.data(), h.shading.size() * sizeof(TriShadingRef));
+    if (vertex_normals && !h.vnormal.empty()) std::memcpy(vertex_normals, h.vnormal.data(), h.vnormal.size() * 4);
+    if (vertex_tex && !h.vtex.empty()) std::memcpy(vertex_tex, h.vtex.data(), h.vtex.size() * 4);
+    return MP_OK;
+}
+
+// ---- rays -------------------------------------------------------------------------------------------------------
+int mp_trace_rays(mp_ctx* ctx, const mp_scene* scene, const float* d_ox, const float* d_oy, const float* d_oz,
+                  const float* d_dx, const float* d_dy, const float* d_dz, uint64_t n, const mp_hits_soa* hits,
+                  void* stream) {
+    if (!ctx || !scene || !hits) return fail(MP_ERR_INVALID, "NULL argument");
+    if (n && (!d_ox || !d_oy || !d_oz || !d_dx || !d_dy || !d_dz)) return fail(MP_ERR_INVALID, "NULL ray array");
+    if (scene->ctx != ctx) return fail(MP_ERR_INVALID, "scene belongs to another context");
+    DeviceGuard g(ctx->device);
+    std::string err;
+    int rc = launch_trace_rays(scene->dev, d_ox, d_oy, d_oz, d_dx, d_dy, d_dz, n, *hits, ctx->cu_count, stream, err);
+    if (rc) return fail(rc, err);
+    return MP_OK;
+}
+
+int mp_generate_rays(mp_ctx* ctx, const mp_camera_sampler* sampler, const mp_settings* settings, mp_block block,
+                     uint32_t sample, float* d_ox, float* d_oy, float* d_oz, float* d_dx, float* d_dy, float* d_dz,
+                     void* stream) {
+    if (!ctx || !sampler || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
+    if (!(block.min_x <= block.max_x && block.min_y <= block.max_y)) return fail(MP_ERR_INVALID, "inverted block");
+    if (!d_ox || !d_oy || !d_oz || !d_dx || !d_dy || !d_dz) return fail(MP_ERR_INVALID, "NULL ray array");
+    DeviceGuard g(ctx->device);
+    std::string err;
+    int rc = launch_generate_rays(*sampler, settings->width, settings->sample_count, settings->seed, block, sample, d_ox,
+                                  d_oy, d_oz, d_dx, d_dy, d_dz, stream, err);
+    if (rc) return fail(rc, err);
+    return MP_OK;
+}
+
+// ---- tiles ------------------------------------------------------------------------------------------------------
+int mp_render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler,
+                           const mp_settings* settings, const mp_block* tiles, size_t n_tiles, float* d_rgba_f32,
+                           void* stream) {
+    if (!ctx || !scene || !sampler || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
+    if (n_tiles && (!tiles || !d_rgba_f32)) return fail(MP_ERR_INVALID, "NULL tiles/output");
+    if (scene->ctx != ctx) return fail(MP_ERR_INVALID, "scene belongs to another context");
+    if (n_tiles == 0) return MP_OK;
+    for (size_t i = 0; i < n_tiles; i++) {
+        const mp_block& t = tiles[i];
+        if (!(t.min_x < t.max_x && t.min_y < t.max_y) || t.max_x - t.min_x > settings->tile_size ||
+            t.max_y - t.min_y > settings->tile_size || t.max_x > settings->width || t.max_y > settings->height)
+            return fail(MP_ERR_INVALID, "tile empty, larger than tile_size, or outside the resolution");
+    }
+    DeviceGuard g(ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mp_block* d_tiles = nullptr;
+    MP_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_tiles), n_tiles * sizeof(mp_block), st));
+    hipError_t e = hipMemcpyAsync(d_tiles, tiles, n_tiles * sizeof(mp_block), hipMemcpyHostToDevice, st);
+    int rc = MP_OK;
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(tiles)");
+    if (!rc) rc = render_tiles_device(ctx, scene, *sampler, *settings, d_tiles, n_tiles, d_rgba_f32, stream);
+    (void)hipFreeAsync(d_tiles, st);
+    return rc;
+}
+
+int mp_untile(mp_ctx* ctx, const mp_settings* settings, const mp_block* tiles, size_t n_tiles, const float* d_tiles_f32,
+              float* d_image_f32, uint8_t* d_image_u8, void* stream) {
+    if (!ctx || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
+    if (n_tiles == 0) return MP_OK;
+    if (!tiles || !d_tiles_f32) return fail(MP_ERR_INVALID, "NULL tiles/input");
+    DeviceGuard g(ctx->device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    mp_block* d_tiles = nullptr;
+    MP_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_tiles), n_tiles * sizeof(mp_block), st));
+    hipError_t e = hipMemcpyAsync(d_tiles, tiles, n_tiles * sizeof(mp_block), hipMemcpyHostToDevice, st);
+    int rc = MP_OK;
+    std::string err;
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(tiles)");
+    if (!rc) {
+        rc = launch_untile(settings->width, settings->height, settings->tile_size, d_tiles, static_cast<uint32_t>(n_tiles),
+                           d_tiles_f32, d_image_f32, d_image_u8, stream, err);
+        if (rc) fail(rc, err);
+    }
+    (void)hipFreeAsync(d_tiles, st);
+    return rc;
+}
+
+int mp_render_tile(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler, const mp_settings* settings,
+                   mp_block tile, float* rgba_f32, uint8_t* rgba_u8) {
+    if (!ctx || !scene || !sampler || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
+    if (!(tile.min_x < tile.max_x && tile.min_y < tile.max_y)) return MP_OK;  // empty tile: internal_points yields nothing
+    const uint32_t ts = settings->tile_size;
+    const uint32_t w = tile.max_x - tile.min_x, h = tile.max_y - tile.min_y;
+    DeviceGuard g(ctx->device);
+    float* d_out = nullptr;
+    const size_t bytes = static_cast<size_t>(ts) * ts * 16;
+    MP_HIP(hipMalloc(reinterpret_cast<void**>(&d_out), bytes));
+    int rc = mp_render_tiles_device(ctx, scene, sampler, settings, &tile, 1, d_out, nullptr);
+    std::vector<float> host(static_cast<size_t>(ts) * ts * 4);
+    if (!rc) {
+        hipError_t e = hipMemcpy(host.data(), d_out, bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(tile)");
+    }
+    (void)hipFree(d_out);
+    if (rc) return rc;
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            const float* p = &host[(static_cast<size_t>(y) * ts + x) * 4];
+            if (rgba_f32) std::memcpy(&rgba_f32[(static_cast<size_t>(y) * w + x) * 4], p, 16);
+            if (rgba_u8)
+                for (int k = 0; k < 4; k++) rgba_u8[(static_cast<size_t>(y) * w + x) * 4 + k] = to_u8(p[k]);
+        }
+    return MP_OK;
+}
+
+}  // extern "C"
+
+// ---- render() / RenderProgress (machinery.rs) -------------------------------------------------------------------
+struct mp_render {
+    mp_ctx* ctx = nullptr;
+    const mp_scene* scene = nullptr;
+    mp_camera_sampler sampler{};
+    mp_settings settings{};
+    mp_tile_started_cb started = nullptr;
+    mp_tile_finished_cb finished = nullptr;
+    void* user = nullptr;
+    std::vector<mp_block> tiles;                // tile_ordering (machinery.rs:41-42)
+    std::atomic<size_t> next_tile{0};           // next_tile_index (machinery.rs:43)
+    std::atomic<size_t> done_tiles{0};
+    std::atomic<bool> finished_flag{false};
+    std::mutex image_mu;                        // Mutex<RgbaImage> (machinery.rs:39)
+    std::vector<uint8_t> image_u8;
+    std::vector<float> image_f32;
+    std::chrono::steady_clock::time_point start;
+    std::mutex end_mu;
+    bool ended = false;
+    std::chrono::nanoseconds elapsed{0};
+    std::thread worker;
+    int status = MP_OK;
+    std::string error;
+};
+
+namespace {
+
+void render_worker(mp_render* r) {
+    mp_ctx* ctx = r->ctx;
+    const mp_settings& st = r->settings;
+    const uint32_t ts = st.tile_size;
+    const size_t per_tile = static_cast<size_t>(ts) * ts * 4;
+    // A batch is what one launch renders: enough 8x8-pixel work units to fill every CU several times over, small
+    // enough that the tile callbacks keep flowing (the reference hands out one tile per worker thread).
+    const size_t units_per_tile = static_cast<size_t>((ts + 7) / 8) * ((ts + 7) / 8);
+    const size_t batch = std::max<size_t>(1, (static_cast<size_t>(ctx->cu_count) * 64 + units_per_tile - 1) / units_per_tile);
+    auto set_error = [&](int code, const std::string& msg) {
+        r->status = code;
+        r->error = msg;
+    };
+    hipStream_t stream = nullptr;
+    float* d_out = nullptr;
+    mp_block* d_tiles = nullptr;
+    std::vector<float> host(batch * per_tile);
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), batch * per_tile * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_tiles), batch * sizeof(mp_block));
+    if (e != hipSuccess) set_error(MP_ERR_HIP, std::string("render worker setup: ") + hipGetErrorString(e));
+
+    const size_t total = r->tiles.size();
+    while (r->status == MP_OK) {
+        // get_next_tile (machinery.rs:205-208): abort() stores `len` so no new tiles are handed out
+        size_t first = r->next_tile.fetch_add(batch, std::memory_order_acq_rel);
+        if (first >= total) break;
+        size_t n = std::min(batch, total - first);
+        const mp_block* t = &r->tiles[first];
+        if (r->started)
+            for (size_t i = 0; i < n; i++) r->started(r->user, t[i]);  // machinery.rs:75
+        e = hipMemcpyAsync(d_tiles, t, n * sizeof(mp_block), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) { set_error(MP_ERR_HIP, std::string("hipMemcpyAsync(tiles): ") + hipGetErrorString(e)); break; }
+        int rc = render_tiles_device(ctx, r->scene, r->sampler, st, d_tiles, n, d_out, stream);
+        if (rc) { set_error(rc, mp_last_error()); break; }
+        e = hipMemcpyAsync(host.data(), d_out, n * per_tile * 4, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { set_error(MP_ERR_HIP, std::string("tile readback: ") + hipGetErrorString(e)); break; }
+        for (size_t i = 0; i < n; i++) {
+            const mp_block& b = t[i];
+            {
+                std::lock_guard<std::mutex> lk(r->image_mu);  // image.lock().copy_from(..) machinery.rs:78-89
+                for (uint32_t y = b.min_y; y < b.max_y; y++)
+                    for (uint32_t x = b.min_x; x < b.max_x; x++) {
+                        const float* p = &host[i * per_tile + (static_cast<size_t>(y - b.min_y) * ts + (x - b.min_x)) * 4];
+                        size_t o = (static_cast<size_t>(y) * st.width + x) * 4;
+                        std::memcpy(&r->image_f32[o], p, 16);
+                        for (int k = 0; k < 4; k++) r->image_u8[o + k] = to_u8(p[k]);
+                    }
+            }
+            size_t done = r->done_tiles.fetch_add(1, std::memory_order_acq_rel) + 1;
+            if (r->finished) r->finished(r->user, b, mp_progress{done, total});  // machinery.rs:93-99
+        }
+    }
+    if (d_out) (void)hipFree(d_out);
+    if (d_tiles) (void)hipFree(d_tiles);
+    if (stream) (void)hipStreamDestroy(stream);
+    {
+        std::lock_guard<std::mutex> lk(r->end_mu);  // machinery.rs:107-113
+        r->elapsed = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - r->start);
+        r->ended = true;
+    }
+    r->finished_flag.store(true, std::memory_order_release);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mp_render_begin(mp_ctx* ctx, const mp_scene* scene, const mp_camera* camera, const mp_settings* settings,
+                    mp_tile_started_cb started, mp_tile_finished_cb finished, void* user, mp_render** out) {
+    if (!ctx || !scene || !camera || !out || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
+    if (scene->ctx != ctx) return fail(MP_ERR_INVALID, "scene belongs to another context");
+    auto r = std::make_unique<mp_render>();
+    r->ctx = ctx;
+    r->scene = scene;
+    r->settings = *settings;
+    camera_build_sampler(*camera, settings->width, settings->height, r->sampler);  // machinery.rs:65
+    r->started = started;
+    r->finished = finished;
+    r->user = user;
+    uint64_t shuffle = 0;
+    if (settings->flags & MP_FLAG_SHUFFLE_TILES)
+        shuffle = static_cast<uint64_t>(std::chrono::steady_clock::now().time_since_epoch().count()) | 1ull;
+    r->tiles = tile_ordering(mp_block{0, 0, settings->width, settings->height}, settings->tile_size, shuffle);
+    r->image_u8.assign(static_cast<size_t>(settings->width) * settings->height * 4, 0);   // RgbaImage::new :34
+    r->image_f32.assign(static_cast<size_t>(settings->width) * settings->height * 4, 0.0f);
+    r->start = std::chrono::steady_clock::now();
+    try {
+        r->worker = std::thread(render_worker, r.get());
+    } catch (const std::exception& ex) {
+        return fail(MP_ERR_UNSUPPORTED, std::string("thread spawn failed: ") + ex.what());  // machinery.rs:116
+    }
+    *out = r.release();
+    return MP_OK;
+}
+
+int mp_render_progress(const mp_render* r, mp_progress* out) {
+    if (!r || !out) return fail(MP_ERR_INVALID, "NULL argument");
+    out->finished = r->done_tiles.load(std::memory_order_acquire);
+    out->total = r->tiles.size();
+    return MP_OK;
+}
+
+int mp_render_is_finished(const mp_render* r, int* finished) {
+    if (!r || !finished) return fail(MP_ERR_INVALID, "NULL argument");
+    *finished = r->finished_flag.load(std::memory_order_acquire) ? 1 : 0;
+    return MP_OK;
+}
+
+int mp_render_elapsed_ns(const mp_render* rc, uint64_t* ns) {
+    if (!rc || !ns) return fail(MP_ERR_INVALID, "NULL argument");
+    mp_render* r = const_cast<mp_render*>(rc);
+    std::lock_guard<std::mutex> lk(r->end_mu);
+    auto d = r->ended ? r->elapsed
+                      : std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - r->start);
+    *ns = static_cast<uint64_t>(d.count());
+    return MP_OK;
+}
+
+int mp_render_abort(mp_render* r) {
+    if (!r) return fail(MP_ERR_INVALID, "NULL argument");
+    r->next_tile.store(r->tiles.size(), std::memory_order_release);  // machinery.rs:161-165
+    return MP_OK;
+}
+
+int mp_render_wait(mp_render* r) {
+    if (!r) return fail(MP_ERR_INVALID, "NULL argument");
+    if (r->worker.joinable()) r->worker.join();
+    if (r->status != MP_OK) return fail(r->status, r->error);
+    return MP_OK;
+}
+
+int mp_render_image_u8(mp_render* r, uint8_t* dst) {
+    if (!r || !dst) return fail(MP_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(r->image_mu);
+    std::memcpy(dst, r->image_u8.data(), r->image_u8.size());
+    return MP_OK;
+}
+
+int mp_render_image_f32(mp_render* r, float* dst) {
+    if (!r || !dst) return fail(MP_ERR_INVALID, "NULL argument");
+    std::lock_guard<std::mutex> lk(r->image_mu);
+    std::memcpy(dst, r->image_f32.data(), r->image_f32.size() * 4);
+    return MP_OK;
+}
+
+void mp_render_destroy(mp_render* r) {
+    if (!r) return;
+    if (r->worker.joinable()) {
+        r->next_tile.store(r->tiles.size(), std::memory_order_release);
+        r->worker.join();
+    }
+    delete r;
+}
+
+}  // extern "C"

@@ -1,0 +1,569 @@
+// gfx950 (CDNA4) kernels for minipath's per-pixel sampling hot path.
+//
+// Lane mapping (DESIGN.md "Kernels"):
+//   * ray generation, shading and accumulation are LANE-PARALLEL: one (pixel, sample) per lane;
+//   * BVH traversal is GROUP-PARALLEL: a 64-wide wavefront is 8 groups of 8 lanes, one ray per group, lane i of a
+//     group owns child i of an inner node / triangle i of a leaf packet -- the reference's 8-wide AVX2 lane i
+//     (ray_bvh_intersection.rs:104-162).  The wavefront keeps a ray queue and eight traversal stacks in LDS;
+//     active rays are compacted into the queue with __ballot + mbcnt and groups pull the next ray when they finish.
+//
+// Arithmetic contract: f32, compiled with -ffp-contract=off; fused multiply-adds only where the reference writes
+// mul_add / mul_sub (util/simba.rs:57-67); IEEE division and sqrt; no fast-math.  The results are bit-identical to
+// the CPU oracle's.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+
+#include "mp_internal.h"
+
+namespace mp {
+namespace {
+
+constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
+constexpr int kQueueFloats = 9 * 64;  // ox,oy,oz,dx,dy,dz,ix,iy,iz x 64 slots ; hit (t,prim,u,v) aliases rows 0..3
+
+__device__ __forceinline__ float as_f(uint32_t u) { return __uint_as_float(u); }
+__device__ __forceinline__ uint32_t as_u(float f) { return __float_as_uint(f); }
+
+// LDS traffic between lanes of ONE wavefront: DS operations of a wave execute in issue order, so only the
+// compiler has to be kept from reordering them.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- 8-lane group collectives on DPP (no LDS traffic) ---------------------------------------------------------
+// row_half_mirror (0x141) pairs lane i with 7-i inside every group of 8; quad_perm [1,0,3,2] (0xB1) and
+// [2,3,0,1] (0x4E) finish the butterfly inside each quad.  All 8 lanes end with the group's reduction.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float group_min_f(float v) {
+    v = fminf(v, dpp_f<0x141>(v));
+    v = fminf(v, dpp_f<0xB1>(v));
+    v = fminf(v, dpp_f<0x4E>(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t group_min_u(uint32_t v) {
+    v = min(v, dpp_u<0x141>(v));
+    v = min(v, dpp_u<0xB1>(v));
+    v = min(v, dpp_u<0x4E>(v));
+    return v;
+}
+
+// ---- RNG: rand 0.9.3 SmallRng = Xoshiro256++ (seeded mode, include/minipath_hip.h) -----------------------------
+struct Rng {
+    uint64_t s0, s1, s2, s3;
+};
+__device__ __forceinline__ uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+__device__ __forceinline__ uint64_t splitmix(uint64_t& state) {
+    state += 0x9e3779b97f4a7c15ull;
+    uint64_t z = state;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ void rng_seed(Rng& r, uint64_t state) {
+    r.s0 = splitmix(state);
+    r.s1 = splitmix(state);
+    r.s2 = splitmix(state);
+    r.s3 = splitmix(state);
+}
+__device__ __forceinline__ uint32_t rng_next_u32(Rng& r) {
+    uint64_t result = rotl64(r.s0 + r.s3, 23) + r.s0;
+    uint64_t t = r.s1 << 17;
+    r.s2 ^= r.s0;
+    r.s3 ^= r.s1;
+    r.s1 ^= r.s2;
+    r.s0 ^= r.s3;
+    r.s2 ^= t;
+    r.s3 = rotl64(r.s3, 45);
+    return static_cast<uint32_t>(result >> 32);
+}
+__device__ __forceinline__ float rng_value0_1(Rng& r) { return as_f(0x3F800000u | (rng_next_u32(r) >> 9)) - 1.0f; }
+
+struct RayGen {
+    mp_camera_sampler s;
+    float jitter_scale;  // UniformFloat::new_inclusive(-0.5, 0.5).scale, computed on the host
+    uint32_t width, spp;
+    uint64_t seed;
+};
+
+struct Ray {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
+};
+
+// geometry/mod.rs:45-54
+__device__ __forceinline__ void ray_new(float ox, float oy, float oz, float dx, float dy, float dz, Ray& r) {
+    float n = sqrtf(dx * dx + dy * dy + dz * dz);
+    r.ox = ox; r.oy = oy; r.oz = oz;
+    r.dx = dx / n; r.dy = dy / n; r.dz = dz / n;
+    r.ix = (r.dx == 0.0f) ? INFINITY : 1.0f / r.dx;
+    r.iy = (r.dy == 0.0f) ? INFINITY : 1.0f / r.dy;
+    r.iz = (r.dz == 0.0f) ? INFINITY : 1.0f / r.dz;
+}
+
+// CameraSampler::sample_ray camera.rs:176-191, seeded per (pixel, sample)
+__device__ __forceinline__ void sample_ray(const RayGen& P, uint32_t x, uint32_t y, uint32_t sample, Ray& r) {
+    Rng rng;
+    rng_seed(rng, P.seed + ((static_cast<uint64_t>(y) * P.width + x) * P.spp + sample));
+    float film_u = static_cast<float>(x) + (rng_value0_1(rng) * P.jitter_scale + (-0.5f));
+    float film_v = static_cast<float>(y) + (rng_value0_1(rng) * P.jitter_scale + (-0.5f));
+    float fv = film_v * P.s.pixel_scale, fu = film_u * P.s.pixel_scale;
+    float fx = P.s.film_origin_offset[0] + P.s.up[0] * fv - P.s.right[0] * fu;
+    float fy = P.s.film_origin_offset[1] + P.s.up[1] * fv - P.s.right[1] * fu;
+    float fz = P.s.film_origin_offset[2] + P.s.up[2] * fv - P.s.right[2] * fu;
+    float x1, x2;
+    for (;;) {  // rand_distr::UnitDisc
+        x1 = rng_value0_1(rng) * 2.0f + (-1.0f);
+        x2 = rng_value0_1(rng) * 2.0f + (-1.0f);
+        if (x1 * x1 + x2 * x2 <= 1.0f) break;
+    }
+    float a = P.s.lens_radius * x1, b = P.s.lens_radius * x2;
+    float lx = P.s.right[0] * a + P.s.up[0] * b;
+    float ly = P.s.right[1] * a + P.s.up[1] * b;
+    float lz = P.s.right[2] * a + P.s.up[2] * b;
+    ray_new(P.s.center[0] + lx, P.s.center[1] + ly, P.s.center[2] + lz, lx * P.s.lens_weight - fx,
+            ly * P.s.lens_weight - fy, lz * P.s.lens_weight - fz, r);
+}
+
+// ---- traversal --------------------------------------------------------------------------------------------------
+// util/simba.rs:57-59
+__device__ __forceinline__ float fma_dot(float ax, float ay, float az, float bx, float by, float bz) {
+    return __builtin_fmaf(az, bz, __builtin_fmaf(ay, by, ax * bx));
+}
+// util/simba.rs:61-67 : mul_sub(a, b, c) = a*b - c, c rounded first
+__device__ __forceinline__ float fms(float a, float b, float c) { return __builtin_fmaf(a, b, -c); }
+
+// Traces `nrays` rays held in the wave's LDS queue `q` (rows ox,oy,oz,dx,dy,dz,ix,iy,iz; slot = column).
+// On return rows 0..3 of each slot hold the closest hit: t (f32::MAX on miss), prim (bits), u, v.
+// impl Object for TriangleBvh::intersect, ray_bvh_intersection.rs:26-96, for 8 rays at a time.
+__device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict__ q, uint2* __restrict__ stack_base,
+                                           int nrays) {
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const int g = lane >> 3, li = lane & 7;
+    uint2* stack = stack_base + g * sc.stack_cap;
+    const uint64_t groups_below = (1ull << (g * 8)) - 1ull;
+    const uint32_t lanes_below = (1u << li) - 1u;
+    const int src_base = lane & ~7;
+
+    int slot = -1, sp = 0, head = 0;
+    uint32_t pk = 0, pk_end = 0, seq = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0;
+    float best_t = FLT_MAX;                 // best.t, group-uniform (ray_bvh_intersection.rs:34-37)
+    float tl = FLT_MAX, ul = 0, vl = 0;     // this lane's earliest closest candidate
+    uint32_t pkl = kNoPrim, seql = 0;
+
+    for (;;) {
+        // -- ray finished: resolve the winner among the 8 lanes.  The reference takes candidates in (packet visit
+        //    order, ascending lane) and replaces on strict `<` (:118-136, :59): the winner is the earliest candidate
+        //    that attains the minimum t.  Every lane kept its own earliest minimum; ties across lanes go to the
+        //    smaller (visit sequence, lane).
+        if (slot >= 0 && sp == 0 && pk == pk_end) {
+            float tmin = group_min_f(tl);
+            uint32_t key = (pkl != kNoPrim && tl == tmin) ? ((seql << 3) | static_cast<uint32_t>(li)) : 0xFFFFFFFFu;
+            uint32_t kmin = group_min_u(key);
+            int wl = src_base | static_cast<int>(kmin & 7u);
+            float wu = __shfl(ul, wl), wv = __shfl(vl, wl);
+            uint32_t wp = static_cast<uint32_t>(__shfl(static_cast<int>(pkl), wl));
+            if (li == 0) {
+                bool hit = kmin != 0xFFFFFFFFu;
+                q[0 * 64 + slot] = hit ? tmin : FLT_MAX;
+                q[1 * 64 + slot] = as_f(hit ? (wp * 8u + (kmin & 7u)) : kNoPrim);
+                q[2 * 64 + slot] = wu;
+                q[3 * 64 + slot] = wv;
+            }
+            slot = -1;
+        }
+        // -- idle groups pull the next rays of the queue (wave-uniform head, no atomics)
+        uint64_t idle = __ballot(slot < 0);
+        if (idle != 0) {
+            uint64_t gm = idle & 0x0101010101010101ull;
+            int mine = head + __popcll(gm & groups_below);
+            head += __popcll(gm);
+            if (slot < 0 && mine < nrays) {
+                slot = mine;
+                ox = q[0 * 64 + mine]; oy = q[1 * 64 + mine]; oz = q[2 * 64 + mine];
+                dx = q[3 * 64 + mine]; dy = q[4 * 64 + mine]; dz = q[5 * 64 + mine];
+                ix = q[6 * 64 + mine]; iy = q[7 * 64 + mine]; iz = q[8 * 64 + mine];
+                best_t = FLT_MAX; tl = FLT_MAX; ul = 0; vl = 0; pkl = kNoPrim; seql = 0; seq = 0;
+                pk = pk_end = 0;
+                sp = 1;
+                if (li == 0) stack[0] = make_uint2(sc.root, as_u(-INFINITY));  // :28-32
+            }
+            if (__ballot(slot >= 0) == 0) break;
+        }
+        wave_lds_sync();
+        // -- A: groups with no pending packet pop one stack entry (:39-62)
+        if (slot >= 0 && pk == pk_end) {
+            sp--;
+            uint2 e = stack[sp];
+            float node_t1 = as_f(e.y);
+            if (!(node_t1 > best_t)) {  // :40-44
+                uint32_t link = e.x;
+                if ((link & 7u) == 0u) {
+                    // InnerNode::intersect :149-162 ; lane li = child li.  Child boxes are stored decompressed
+                    // (SURVEY A.4 box chain evaluated once on the host), so the slab test starts directly.
+                    const float* nd = sc.nodes + static_cast<size_t>(link >> 3) * kNodeDwords + li;
+                    float bnx = nd[0], bny = nd[8], bnz = nd[16], bxx = nd[24], bxy = nd[32], bxz = nd[40];
+                    uint32_t child = as_u(nd[48]);
+                    // aabb.rs:254-284
+                    float ax = (bnx - ox) * ix, ay = (bny - oy) * iy, az = (bnz - oz) * iz;
+                    float cx = (bxx - ox) * ix, cy = (bxy - oy) * iy, cz = (bxz - oz) * iz;
+                    ax = (ax != ax) ? -INFINITY : ax; ay = (ay != ay) ? -INFINITY : ay; az = (az != az) ? -INFINITY : az;
+                    cx = (cx != cx) ? INFINITY : cx; cy = (cy != cy) ? INFINITY : cy; cz = (cz != cz) ? INFINITY : cz;
+                    float lox = fminf(ax, cx), loy = fminf(ay, cy), loz = fminf(az, cz);
+                    float hix = fmaxf(ax, cx), hiy = fmaxf(ay, cy), hiz = fmaxf(az, cz);
+                    float t1 = fmaxf(fmaxf(lox, 0.0f), fmaxf(loy, loz));
+                    float t2 = fminf(fminf(hix, best_t), fminf(hiy, hiz));
+                    bool ok = (t1 <= t2) && (child != MP_LINK_NULL);  // Null links are skipped at pop in the reference (:49)
+                    uint32_t m = static_cast<uint32_t>(__ballot(ok) >> (g * 8)) & 0xFFu;
+                    if (ok) stack[sp + __popc(m & lanes_below)] = make_uint2(child, as_u(t1));  // ascending lane :161
+                    sp += __popc(m);
+                } else {
+                    pk = link >> 3;  // Leaf :56-62
+                    pk_end = pk + (link & 7u);
+                }
+            }
+        }
+        // -- B: one leaf packet per iteration (:104-140) ; lane li = triangle li
+        if (slot >= 0 && pk < pk_end) {
+            const float* tp = sc.tris + static_cast<size_t>(pk) * kPacketDwords + li;
+            float v0x = tp[0], v0y = tp[8], v0z = tp[16];
+            float e1x = tp[24], e1y = tp[32], e1z = tp[40];
+            float e2x = tp[48], e2y = tp[56], e2z = tp[64];
+            // triangle.rs:183-217
+            float hx = fms(dy, e2z, dz * e2y), hy = fms(dz, e2x, dx * e2z), hz = fms(dx, e2y, dy * e2x);
+            float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
+            float inv_det = 1.0f / det;
+            float sx = ox - v0x, sy = oy - v0y, sz = oz - v0z;
+            float u = inv_det * fma_dot(sx, sy, sz, hx, hy, hz);
+            float qx = fms(sy, e1z, sz * e1y), qy = fms(sz, e1x, sx * e1z), qz = fms(sx, e1y, sy * e1x);
+            float v = inv_det * fma_dot(dx, dy, dz, qx, qy, qz);
+            float t = inv_det * fma_dot(e2x, e2y, e2z, qx, qy, qz);
+            bool valid = (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) & (t >= 0.0f) & (t <= best_t);  // :125
+            if (valid && t < tl) { tl = t; ul = u; vl = v; pkl = pk; seql = seq; }
+            seq++;
+            pk++;
+            if (pk == pk_end) best_t = group_min_f(tl);  // `if hit.t < best.t { best = hit }` :59-61
+        }
+    }
+    wave_lds_sync();
+}
+
+// Hit resolve + shade: tail of intersect (ray_bvh_intersection.rs:66-95) and render_sample (worker.rs:59-65).
+// Returns |dot(ray.direction, normal)|.
+__device__ __forceinline__ void resolve_normal(const DevScene& sc, uint32_t prim, float u, float v, float n[3]) {
+    const float4* sh = reinterpret_cast<const float4*>(sc.shade) + static_cast<size_t>(prim) * 3;
+    float4 a = sh[0], b = sh[1], c = sh[2];
+    float nx, ny, nz;
+    if (as_u(c.y) != 0u) {
+        // flat: Triangle::normal (triangle.rs:141-144), unfused cross of the decompressed edges
+        const float* tp = sc.tris + static_cast<size_t>(prim >> 3) * kPacketDwords + (prim & 7u);
+        float e1x = tp[24], e1y = tp[32], e1z = tp[40], e2x = tp[48], e2y = tp[56], e2z = tp[64];
+        nx = e1y * e2z - e1z * e2y;
+        ny = e1z * e2x - e1x * e2z;
+        nz = e1x * e2y - e1y * e2x;
+    } else {
+        float w = 1.0f - u - v;  // triangle.rs:235-236
+        nx = a.x * w + a.w * u + b.z * v;
+        ny = a.y * w + b.x * u + b.w * v;
+        nz = a.z * w + b.y * u + c.x * v;
+    }
+    float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    n[0] = nx / len; n[1] = ny / len; n[2] = nz / len;
+}
+
+// ---- fused tile render: Worker::render_tile (worker.rs:32-49) for a list of tiles -----------------------------
+struct RenderParams {
+    DevScene scene;
+    RayGen gen;
+    const mp_block* tiles;
+    uint32_t n_tiles, tile_size;
+    float* out;           // tile-major RGBA f32
+    uint32_t* counter;    // work-queue head
+    float inv_spp;        // 1.0 / spp as f32 (worker.rs:44)
+    uint32_t lds_per_wave;
+};
+
+// S = samples of one pixel in flight in a wavefront (64/S pixels x S consecutive samples per pass).
+template <int S>
+__global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int BW = (S == 1) ? 8 : (S == 2) ? 8 : (S == 4) ? 4 : 4;
+    constexpr int BH = 64 / S / BW;
+    const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
+    float* q = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P.lds_per_wave);
+    uint2* stack = reinterpret_cast<uint2*>(q + kQueueFloats);
+    const uint32_t ts = P.tile_size;
+    const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by;
+    const uint32_t total = P.n_tiles * upt;
+    const uint64_t lanes_lt = (1ull << lane) - 1ull;
+    const int pix = lane / S, sub = lane % S;
+    const uint32_t spp = P.gen.spp;
+
+    for (;;) {
+        uint32_t unit = 0;
+        if (lane == 0) unit = atomicAdd(P.counter, 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        if (unit >= total) break;
+        const uint32_t tile_i = unit / upt, b = unit % upt;
+        const mp_block T = P.tiles[tile_i];
+        const uint32_t px = T.min_x + (b % bx) * BW + static_cast<uint32_t>(pix % BW);
+        const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
+        const bool inpix = px < T.max_x && py < T.max_y;
+        if (__ballot(inpix) == 0) continue;
+        float acc = 0.0f, cnt = 0.0f;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
+        for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+            const uint32_t s = s0 + static_cast<uint32_t>(sub);
+            const bool act = inpix && s < spp;
+            Ray r;
+            r.dx = r.dy = r.dz = 0.0f;
+            if (act) sample_ray(P.gen, px, py, s, r);
+            // compaction of the active lanes into the wave's ray queue
+            const uint64_t am = __ballot(act);
+            const int n = __popcll(am), rank = __popcll(am & lanes_lt);
+            if (act) {
+                q[0 * 64 + rank] = r.ox; q[1 * 64 + rank] = r.oy; q[2 * 64 + rank] = r.oz;
+                q[3 * 64 + rank] = r.dx; q[4 * 64 + rank] = r.dy; q[5 * 64 + rank] = r.dz;
+                q[6 * 64 + rank] = r.ix; q[7 * 64 + rank] = r.iy; q[8 * 64 + rank] = r.iz;
+            }
+            wave_lds_sync();
+            trace_wave(P.scene, q, stack, n);
+            float c = 0.0f, h = 0.0f;
+            if (act) {
+                uint32_t prim = as_u(q[1 * 64 + rank]);
+                if (prim != kNoPrim) {
+                    float nn[3];
+                    resolve_normal(P.scene, prim, q[2 * 64 + rank], q[3 * 64 + rank], nn);
+                    c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60
+                    h = 1.0f;
+                }
+            }
+            wave_lds_sync();
+            // pixel_sum += sample, strictly in sample order (worker.rs:41-43); inactive samples add +0.0 (exact)
+#pragma unroll
+            for (int j = 0; j < S; j++) {
+                acc += __shfl(c, (lane & ~(S - 1)) + j);
+                cnt += __shfl(h, (lane & ~(S - 1)) + j);
+            }
+        }
+        if (inpix && sub == 0) {
+            float m = acc * P.inv_spp;  // worker.rs:44
+            float4 o = make_float4(m, m, m, cnt * P.inv_spp);
+            size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
+            *reinterpret_cast<float4*>(P.out + off) = o;
+        }
+    }
+}
+
+// ---- batched Object::intersect over SoA ray streams (ray_bvh_intersection.rs:26-96) -------------------------
+struct TraceParams {
+    DevScene scene;
+    const float *ox, *oy, *oz, *dx, *dy, *dz;
+    uint64_t n;
+    mp_hits_soa hits;
+    uint32_t lds_per_wave;
+};
+
+__global__ __launch_bounds__(256) void trace_rays_kernel(TraceParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
+    float* q = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P.lds_per_wave);
+    uint2* stack = reinterpret_cast<uint2*>(q + kQueueFloats);
+    const uint64_t chunks = (P.n + 63) / 64;
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
+    for (uint64_t chunk = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave; chunk < chunks; chunk += stride) {
+        const uint64_t i = chunk * 64 + lane;
+        const bool act = i < P.n;
+        const int n = static_cast<int>(min(static_cast<uint64_t>(64), P.n - chunk * 64));
+        Ray r;
+        r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = 0.0f;
+        if (act) {
+            ray_new(P.ox[i], P.oy[i], P.oz[i], P.dx[i], P.dy[i], P.dz[i], r);
+            q[0 * 64 + lane] = r.ox; q[1 * 64 + lane] = r.oy; q[2 * 64 + lane] = r.oz;
+            q[3 * 64 + lane] = r.dx; q[4 * 64 + lane] = r.dy; q[5 * 64 + lane] = r.dz;
+            q[6 * 64 + lane] = r.ix; q[7 * 64 + lane] = r.iy; q[8 * 64 + lane] = r.iz;
+        }
+        wave_lds_sync();
+        trace_wave(P.scene, q, stack, n);
+        if (act) {
+            float t = q[0 * 64 + lane];
+            uint32_t prim = as_u(q[1 * 64 + lane]);
+            float u = q[2 * 64 + lane], v = q[3 * 64 + lane];
+            if (P.hits.d_t) P.hits.d_t[i] = t;
+            if (P.hits.d_prim) P.hits.d_prim[i] = prim;
+            if (P.hits.d_u) P.hits.d_u[i] = u;
+            if (P.hits.d_v) P.hits.d_v[i] = v;
+            if (P.hits.d_point || P.hits.d_normal || P.hits.d_tex) {
+                float pt[3] = {0, 0, 0}, nn[3] = {0, 0, 0}, tx[3] = {0, 0, 0};
+                if (prim != kNoPrim) {
+                    resolve_normal(P.scene, prim, u, v, nn);
+                    pt[0] = r.ox + r.dx * t; pt[1] = r.oy + r.dy * t; pt[2] = r.oz + r.dz * t;  // geometry/mod.rs:56-58
+                    const uint32_t* vi = P.scene.vidx + static_cast<size_t>(prim) * 3;
+                    const float *t0 = P.scene.vtex + 3 * static_cast<size_t>(vi[0]), *t1 = P.scene.vtex + 3 * static_cast<size_t>(vi[1]),
+                                *t2 = P.scene.vtex + 3 * static_cast<size_t>(vi[2]);
+                    float w = 1.0f - u - v;
+                    for (int k = 0; k < 3; k++) tx[k] = t0[k] * w + t1[k] * u + t2[k] * v;
+                }
+                for (int k = 0; k < 3; k++) {
+                    if (P.hits.d_point) P.hits.d_point[i * 3 + k] = pt[k];
+                    if (P.hits.d_normal) P.hits.d_normal[i * 3 + k] = nn[k];
+                    if (P.hits.d_tex) P.hits.d_tex[i * 3 + k] = tx[k];
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+// ---- CameraSampler::sample_ray batched (camera.rs:176-191) -----------------------------------------------------
+__global__ __launch_bounds__(256) void generate_rays_kernel(RayGen G, mp_block blk, uint32_t sample, float* ox, float* oy,
+                                                            float* oz, float* dx, float* dy, float* dz) {
+    const uint32_t w = blk.max_x - blk.min_x, h = blk.max_y - blk.min_y;
+    const uint64_t n = static_cast<uint64_t>(w) * h;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        Ray r;
+        sample_ray(G, blk.min_x + static_cast<uint32_t>(i % w), blk.min_y + static_cast<uint32_t>(i / w), sample, r);
+        ox[i] = r.ox; oy[i] = r.oy; oz[i] = r.oz;
+        dx[i] = r.dx; dy[i] = r.dy; dz[i] = r.dz;
+    }
+}
+
+// ---- tile buffer -> image (machinery.rs:78-89) + color_to_image (worker.rs:69-76) ----------------------------
+__device__ __forceinline__ uint8_t to_u8(float c) {
+    float x = roundf(c * 255.0f);  // half away from zero
+    if (x != x) return 0;          // `as u8` on NaN
+    x = fminf(fmaxf(x, 0.0f), 255.0f);
+    return static_cast<uint8_t>(x);
+}
+
+__global__ __launch_bounds__(256) void untile_kernel(uint32_t width, uint32_t height, uint32_t ts, const mp_block* tiles,
+                                                     uint32_t n_tiles, const float* src, float* img_f32, uint8_t* img_u8) {
+    const uint64_t per_tile = static_cast<uint64_t>(ts) * ts;
+    const uint64_t n = per_tile * n_tiles;
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const uint32_t tile_i = static_cast<uint32_t>(i / per_tile), p = static_cast<uint32_t>(i % per_tile);
+        const mp_block T = tiles[tile_i];
+        const uint32_t x = T.min_x + p % ts, y = T.min_y + p / ts;
+        if (x >= T.max_x || y >= T.max_y || x >= width || y >= height) continue;
+        const float4 v = *reinterpret_cast<const float4*>(src + i * 4);
+        const size_t o = (static_cast<size_t>(y) * width + x) * 4;
+        if (img_f32) *reinterpret_cast<float4*>(img_f32 + o) = v;
+        if (img_u8) {
+            uchar4 c = make_uchar4(to_u8(v.x), to_u8(v.y), to_u8(v.z), to_u8(v.w));
+            *reinterpret_cast<uchar4*>(img_u8 + o) = c;
+        }
+    }
+}
+
+// UniformFloat::new_inclusive(low, high).scale (rand 0.9): (high-low)/max_rand, reduced by ulps until
+// scale*max_rand + low <= high
+float uniform_inclusive_scale(float low, float high) {
+    const float max_rand = 1.0f - FLT_EPSILON;
+    float scale = (high - low) / max_rand;
+    for (;;) {
+        volatile float top = scale * max_rand;
+        top = top + low;
+        if (!(top > high)) break;
+        uint32_t b;
+        __builtin_memcpy(&b, &scale, 4);
+        b -= 1;
+        __builtin_memcpy(&scale, &b, 4);
+    }
+    return scale;
+}
+
+uint32_t lds_bytes_per_wave(uint32_t stack_cap) { return static_cast<uint32_t>(kQueueFloats * 4 + 8u * stack_cap * 8u); }
+
+int check(hipError_t e, const char* what, std::string& err) {
+    if (e == hipSuccess) return MP_OK;
+    err = std::string(what) + ": " + hipGetErrorString(e);
+    return MP_ERR_HIP;
+}
+
+}  // namespace
+
+int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (L.n_tiles == 0) return MP_OK;
+    RenderParams P;
+    P.scene = L.scene;
+    P.gen.s = L.sampler;
+    P.gen.jitter_scale = uniform_inclusive_scale(-0.5f, 0.5f);
+    P.gen.width = L.width;
+    P.gen.spp = L.spp;
+    P.gen.seed = L.seed;
+    P.tiles = L.d_tiles;
+    P.n_tiles = L.n_tiles;
+    P.tile_size = L.tile_size;
+    P.out = L.d_out;
+    P.counter = L.d_counter;
+    P.inv_spp = 1.0f / static_cast<float>(L.spp);
+    P.lds_per_wave = lds_bytes_per_wave(L.scene.stack_cap);
+    const uint32_t lds = P.lds_per_wave * 4;
+    if (lds > 160 * 1024) { err = "scene too deep for the LDS traversal stacks"; return MP_ERR_UNSUPPORTED; }
+    int rc = check(hipMemsetAsync(L.d_counter, 0, sizeof(uint32_t), st), "hipMemsetAsync(counter)", err);
+    if (rc) return rc;
+    const uint64_t units = static_cast<uint64_t>(L.n_tiles) * ((L.tile_size + 7) / 8) * ((L.tile_size + 7) / 8);
+    const uint64_t want = (units + 3) / 4;
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * 8));
+    hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);
+    return check(hipGetLastError(), "render_tiles_kernel launch", err);
+}
+
+int launch_trace_rays(const DevScene& sc, const float* ox, const float* oy, const float* oz, const float* dx,
+                      const float* dy, const float* dz, uint64_t n, const mp_hits_soa& hits, int cu_count, void* stream,
+                      std::string& err) {
+    if (n == 0) return MP_OK;
+    TraceParams P;
+    P.scene = sc;
+    P.ox = ox; P.oy = oy; P.oz = oz; P.dx = dx; P.dy = dy; P.dz = dz;
+    P.n = n;
+    P.hits = hits;
+    P.lds_per_wave = lds_bytes_per_wave(sc.stack_cap);
+    const uint32_t lds = P.lds_per_wave * 4;
+    if (lds > 160 * 1024) { err = "scene too deep for the LDS traversal stacks"; return MP_ERR_UNSUPPORTED; }
+    const uint64_t chunks = (n + 63) / 64, want = (chunks + 3) / 4;
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(cu_count) * 8));
+    hipLaunchKernelGGL(trace_rays_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), P);
+    return check(hipGetLastError(), "trace_rays_kernel launch", err);
+}
+
+int launch_generate_rays(const mp_camera_sampler& s, uint32_t width, uint32_t spp, uint64_t seed, mp_block block,
+                         uint32_t sample, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz, void* stream,
+                         std::string& err) {
+    const uint64_t n = static_cast<uint64_t>(block.max_x - block.min_x) * (block.max_y - block.min_y);
+    if (n == 0) return MP_OK;
+    RayGen G;
+    G.s = s;
+    G.jitter_scale = uniform_inclusive_scale(-0.5f, 0.5f);
+    G.width = width;
+    G.spp = spp;
+    G.seed = seed;
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 8192));
+    hipLaunchKernelGGL(generate_rays_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), G, block, sample, ox,
+                       oy, oz, dx, dy, dz);
+    return check(hipGetLastError(), "generate_rays_kernel launch", err);
+}
+
+int launch_untile(uint32_t width, uint32_t height, uint32_t tile_size, const mp_block* d_tiles, uint32_t n_tiles,
+                  const float* d_tiles_f32, float* d_image_f32, uint8_t* d_image_u8, void* stream, std::string& err) {
+    const uint64_t n = static_cast<uint64_t>(tile_size) * tile_size * n_tiles;
+    if (n == 0) return MP_OK;
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 8192));
+    hipLaunchKernelGGL(untile_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), width, height, tile_size,
+                       d_tiles, n_tiles, d_tiles_f32, d_image_f32, d_image_u8);
+    return check(hipGetLastError(), "untile_kernel launch", err);
+}
+
+}  // namespace mp

@@ -1,0 +1,112 @@
+// Internal declarations shared by the host sources and the HIP kernels of libminipath_hip.so.
+// Nothing here is part of the C ABI (include/minipath_hip.h is).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/minipath_hip.h"
+
+namespace mp {
+
+// ---- reference-layout host structures (triangle_bvh/mod.rs:33-45, compressed_geometry.rs) -----------------
+struct InnerNodeRef {       // 128 B
+    uint16_t bmin[3][8];
+    uint16_t bmax[3][8];
+    uint32_t link[8];
+};
+struct TriPacketRef {       // 144 B
+    uint16_t v[3][3][8];    // [vertex][coord][lane]
+};
+struct TriShadingRef {      // 16 B
+    uint32_t vi[3];
+    uint32_t flat;
+};
+static_assert(sizeof(InnerNodeRef) == 128, "InnerNode layout");
+static_assert(sizeof(TriPacketRef) == 144, "RelativeTriangle8 layout");
+
+struct Box3 {
+    float mn[3], mx[3];
+};
+
+// Result of the host pre-pass (building.rs).  `node_box` / `leaf_box` hold the decompressed enclosing box of
+// every inner node / of every leaf (keyed by the leaf's first packet), i.e. the box chain of SURVEY A.4.
+struct HostBvh {
+    Box3 bbox{};
+    uint32_t root = MP_LINK_NULL;
+    uint32_t depth = 0;
+    uint32_t triangle_count = 0;
+    std::vector<InnerNodeRef> inner;
+    std::vector<Box3> inner_box;          // enclosing box each inner node was built against
+    std::vector<TriPacketRef> packets;
+    std::vector<Box3> packet_box;         // enclosing (leaf) box of each packet
+    std::vector<TriShadingRef> shading;   // packets*8
+    std::vector<float> vnormal, vtex;     // nv*3
+    uint32_t vertex_count = 0;
+};
+
+// building.rs:83-107.  Returns MP_OK or an error code with `err` filled.
+int build_bvh(const float* pos, const float* nrm, const float* tex, uint32_t nv, const uint32_t* tri, uint32_t nt,
+              HostBvh& out, std::string& err);
+// building.rs:28-81
+int load_obj(const char* path, std::vector<float>& pos, std::vector<float>& nrm, std::vector<float>& tex,
+             std::vector<uint32_t>& tri, std::string& err);
+
+// ---- device scene ("traversal format") -------------------------------------------------------
+// nodes : inner_count x 56 dwords : rows minx,miny,minz,maxx,maxy,maxz (f32[8] each, absolute decompressed child
+//         boxes) followed by link[8] (u32).  224 B per node.
+// tris  : packet_count x 72 dwords : rows v0x,v0y,v0z,e1x,e1y,e1z,e2x,e2y,e2z (f32[8] each): decompressed v0 and
+//         the edges e1=v1-v0, e2=v2-v0 of triangle.rs:195-196.  288 B per packet.
+// shade : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) pad pad.  48 B per triangle slot.
+// vidx/vtex : for the full HitRecord (texture_coords).
+struct DevScene {
+    const float* nodes = nullptr;
+    const float* tris = nullptr;
+    const float* shade = nullptr;
+    const uint32_t* vidx = nullptr;  // packets*8*3
+    const float* vtex = nullptr;     // nv*3
+    uint32_t root = MP_LINK_NULL;
+    uint32_t inner_count = 0;
+    uint32_t packet_count = 0;
+    uint32_t stack_cap = 1;          // 7*depth+1
+};
+
+constexpr int kNodeDwords = 56;
+constexpr int kPacketDwords = 72;
+
+// ---- kernel launchers (kernels.hip) ---------------------------------------------------------------------
+struct RenderLaunch {
+    DevScene scene;
+    mp_camera_sampler sampler;
+    uint32_t width, height, spp, tile_size;
+    uint64_t seed;
+    const mp_block* d_tiles;   // device copy of the tile list
+    uint32_t n_tiles;
+    float* d_out;              // tile-major f32 RGBA
+    uint32_t* d_counter;       // work-queue head, zeroed by the launcher
+    int cu_count;
+};
+
+int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err);
+int launch_trace_rays(const DevScene& sc, const float* ox, const float* oy, const float* oz, const float* dx,
+                      const float* dy, const float* dz, uint64_t n, const mp_hits_soa& hits, int cu_count, void* stream,
+                      std::string& err);
+int launch_generate_rays(const mp_camera_sampler& s, uint32_t width, uint32_t spp, uint64_t seed, mp_block block,
+                         uint32_t sample, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz, void* stream,
+                         std::string& err);
+int launch_untile(uint32_t width, uint32_t height, uint32_t tile_size, const mp_block* d_tiles, uint32_t n_tiles,
+                  const float* d_tiles_f32, float* d_image_f32, uint8_t* d_image_u8, void* stream, std::string& err);
+
+// camera / tiles (host_camera.cpp)
+void camera_default(mp_camera& c);
+void camera_look_at(mp_camera& c, const float eye[3], const float at[3], const float up[3]);
+void camera_look_direction(mp_camera& c, const float eye[3], const float fwd[3], const float up[3]);
+void camera_basis(const mp_camera& c, float center[3], float fwd[3], float up[3], float right[3]);
+void camera_build_sampler(const mp_camera& c, uint32_t w, uint32_t h, mp_camera_sampler& out);
+std::vector<mp_block> tile_ordering(mp_block block, uint32_t tile_size, uint64_t shuffle_seed);
+
+void set_last_error(const std::string& s);
+
+}  // namespace mp

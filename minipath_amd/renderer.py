@@ -1,0 +1,200 @@
+"""Mirror of src/renderer: RenderSettings (mod.rs:7-13), render() and RenderProgress (machinery.rs:20-178),
+Worker::render_tile (worker.rs:32-49)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .camera import Camera, CameraSampler
+from .scene import Context, Scene
+from .screen_block import ScreenBlock, tile_ordering
+
+
+@dataclass(frozen=True)
+class RenderSettings:
+    """renderer/mod.rs:7-13 plus the build-defined seed of the reproducible sample stream."""
+
+    tile_size: int
+    sample_count: int
+    resolution: tuple
+    seed: int = 0x5EED
+    shuffle_tiles: bool = False
+
+    def as_struct(self) -> _lib.SettingsStruct:
+        if self.tile_size <= 0 or self.sample_count <= 0:
+            raise ValueError("tile_size and sample_count are NonZeroU32")
+        return _lib.SettingsStruct(
+            int(self.tile_size), int(self.sample_count), int(self.resolution[0]), int(self.resolution[1]),
+            int(self.seed) & 0xFFFFFFFFFFFFFFFF, _lib.MP_FLAG_SHUFFLE_TILES if self.shuffle_tiles else 0, 0,
+        )
+
+
+@dataclass(frozen=True)
+class RenderProgressSnapshot:
+    """machinery.rs:180-189."""
+
+    finished: int
+    total: int
+
+    def percent(self) -> float:
+        return 100.0 * self.finished / self.total
+
+
+class RenderProgress:
+    """machinery.rs:125-178."""
+
+    def __init__(self, handle, settings: RenderSettings, keepalive):
+        self._h = handle
+        self._settings = settings
+        self._keepalive = keepalive  # callbacks + scene must outlive the worker thread
+
+    def progress(self) -> RenderProgressSnapshot:
+        p = _lib.Progress()
+        _lib.check(_lib.lib().mp_render_progress(self._h, C.byref(p)))
+        return RenderProgressSnapshot(p.finished, p.total)
+
+    def is_finished(self) -> bool:
+        f = C.c_int()
+        _lib.check(_lib.lib().mp_render_is_finished(self._h, C.byref(f)))
+        return bool(f.value)
+
+    def elapsed(self) -> float:
+        ns = C.c_uint64()
+        _lib.check(_lib.lib().mp_render_elapsed_ns(self._h, C.byref(ns)))
+        return ns.value * 1e-9
+
+    def abort(self) -> None:
+        _lib.check(_lib.lib().mp_render_abort(self._h))
+
+    def wait(self) -> None:
+        _lib.check(_lib.lib().mp_render_wait(self._h))
+
+    def image(self) -> np.ndarray:
+        """RGBA u8 [h, w, 4] (copy taken under the image lock)."""
+        w, h = self._settings.resolution
+        out = np.zeros((h, w, 4), np.uint8)
+        _lib.check(_lib.lib().mp_render_image_u8(self._h, out.ctypes.data))
+        return out
+
+    def image_f32(self) -> np.ndarray:
+        """Pre-quantisation per-pixel means (worker.rs:44), [h, w, 4] f32."""
+        w, h = self._settings.resolution
+        out = np.zeros((h, w, 4), np.float32)
+        _lib.check(_lib.lib().mp_render_image_f32(self._h, out.ctypes.data))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().mp_render_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render(
+    scene: Scene,
+    camera: Camera,
+    settings: RenderSettings,
+    started_tile_callback: Optional[Callable[[ScreenBlock], None]] = None,
+    finished_tile_callback: Optional[Callable[[ScreenBlock, RenderProgressSnapshot], None]] = None,
+) -> RenderProgress:
+    """render() (machinery.rs:20-123): asynchronous; callbacks run on the library's worker thread."""
+    bvh = scene.object
+    if bvh.ctx is None:
+        raise _lib.MinipathError(1, "scene is host-only: build it with a Context")
+
+    def _started(_user, blk):
+        if started_tile_callback:
+            started_tile_callback(ScreenBlock(*blk.as_tuple()))
+
+    def _finished(_user, blk, prog):
+        if finished_tile_callback:
+            finished_tile_callback(ScreenBlock(*blk.as_tuple()), RenderProgressSnapshot(prog.finished, prog.total))
+
+    cb1, cb2 = _lib.STARTED_CB(_started), _lib.FINISHED_CB(_finished)
+    h = C.c_void_p()
+    cam = camera._struct()
+    st = settings.as_struct()
+    _lib.check(_lib.lib().mp_render_begin(bvh.ctx.handle, bvh.handle, C.byref(cam), C.byref(st), cb1, cb2, None, C.byref(h)))
+    return RenderProgress(h, settings, (cb1, cb2, scene))
+
+
+def render_tile(scene: Scene, sampler: CameraSampler, settings: RenderSettings, tile: ScreenBlock):
+    """Worker::render_tile (worker.rs:32-49), synchronous: returns (f32 means [h,w,4], u8 [h,w,4])."""
+    bvh = scene.object
+    if bvh.ctx is None:
+        raise _lib.MinipathError(1, "scene is host-only: build it with a Context")
+    w, h = tile.width(), tile.height()
+    f = np.zeros((max(h, 0), max(w, 0), 4), np.float32)
+    u8 = np.zeros((max(h, 0), max(w, 0), 4), np.uint8)
+    s = sampler.as_struct()
+    st = settings.as_struct()
+    _lib.check(
+        _lib.lib().mp_render_tile(bvh.ctx.handle, bvh.handle, C.byref(s), C.byref(st), tile.as_struct(), f.ctypes.data, u8.ctypes.data)
+    )
+    return f, u8
+
+
+class FrameRenderer:
+    """Throughput path: renders a list of tiles into a tile-major HBM buffer in ONE launch on the current torch
+    stream (mp_render_tiles_device) and scatters them into an image (mp_untile).  Used by bench.py and by the
+    multi-GPU driver; torch only provides the device memory and the stream."""
+
+    def __init__(self, scene: Scene, camera: Camera, settings: RenderSettings, tiles: Optional[Sequence[ScreenBlock]] = None):
+        import torch
+
+        bvh = scene.object
+        if bvh.ctx is None:
+            raise _lib.MinipathError(1, "scene is host-only: build it with a Context")
+        self.scene, self.settings = scene, settings
+        self.ctx: Context = bvh.ctx
+        self.device = torch.device("cuda", self.ctx.device_id)
+        w, h = settings.resolution
+        self.tiles: List[ScreenBlock] = list(tiles) if tiles is not None else tile_ordering(ScreenBlock(0, 0, w, h), settings.tile_size)
+        self._tiles_c = (_lib.Block * max(len(self.tiles), 1))(*[t.as_struct() for t in self.tiles])
+        self._sampler = camera.build_sampler(settings.resolution).as_struct()
+        self._st = settings.as_struct()
+        ts = settings.tile_size
+        self.tile_buf = torch.zeros((max(len(self.tiles), 1), ts, ts, 4), dtype=torch.float32, device=self.device)
+        self.rays_per_frame = sum(t.area() for t in self.tiles) * settings.sample_count
+
+    def _stream(self):
+        import torch
+
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def render(self):
+        """One pass of the hot path over this renderer's tiles; asynchronous on the current stream."""
+        _lib.check(
+            _lib.lib().mp_render_tiles_device(
+                self.ctx.handle, self.scene.object.handle, C.byref(self._sampler), C.byref(self._st), self._tiles_c,
+                len(self.tiles), self.tile_buf.data_ptr(), self._stream(),
+            )
+        )
+        return self.tile_buf
+
+    def untile(self, tile_buf=None, tiles: Optional[Sequence[ScreenBlock]] = None, want_u8: bool = True):
+        """Tile-major -> image-major f32 (+ u8 via color_to_image) on the device."""
+        import torch
+
+        w, h = self.settings.resolution
+        buf = self.tile_buf if tile_buf is None else tile_buf
+        tl = self.tiles if tiles is None else list(tiles)
+        tiles_c = self._tiles_c if tiles is None else (_lib.Block * max(len(tl), 1))(*[t.as_struct() for t in tl])
+        img = torch.zeros((h, w, 4), dtype=torch.float32, device=self.device)
+        img8 = torch.zeros((h, w, 4), dtype=torch.uint8, device=self.device) if want_u8 else None
+        _lib.check(
+            _lib.lib().mp_untile(
+                self.ctx.handle, C.byref(self._st), tiles_c, len(tl), buf.data_ptr(), img.data_ptr(),
+                img8.data_ptr() if img8 is not None else None, self._stream(),
+            )
+        )
+        return img, img8

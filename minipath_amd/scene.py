@@ -1,0 +1,146 @@
+"""Mirror of src/scene: Scene<O> / TriangleBvh (scene/mod.rs:7-15, scene/triangle_bvh/mod.rs:20-30)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+
+class Context:
+    """One GPU (include/minipath_hip.h: one context drives one device)."""
+
+    def __init__(self, device_id: int = 0):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().mp_ctx_create(int(device_id), C.byref(h)))
+        self.handle = h
+        self.device_id = int(device_id)
+
+    @property
+    def cu_count(self) -> int:
+        cu = C.c_int()
+        _lib.check(_lib.lib().mp_ctx_device(self.handle, None, C.byref(cu)))
+        return cu.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().mp_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TriangleBvh:
+    """scene/triangle_bvh/mod.rs:20-30.  Built on the host (building.rs), resident in HBM when a Context is given."""
+
+    def __init__(self, handle, ctx: Optional[Context]):
+        self.handle = handle
+        self.ctx = ctx
+
+    @classmethod
+    def with_obj(cls, path: str, ctx: Optional[Context] = None) -> "TriangleBvh":
+        """TriangleBvh::with_obj (building.rs:28-34).  ctx=None builds a host-only BVH (no GPU needed)."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().mp_scene_from_obj(ctx.handle if ctx else None, str(path).encode(), C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def build(cls, positions, normals, tex, triangles, ctx: Optional[Context] = None) -> "TriangleBvh":
+        """TriangleBvh::build (building.rs:83-107) over indexed triangles."""
+        pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        nv = pos.shape[0]
+        nrm = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(nv, 3)
+        tx = None if tex is None else np.ascontiguousarray(tex, np.float32).reshape(nv, 3)
+        tri = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        h = C.c_void_p()
+        _lib.check(
+            _lib.lib().mp_scene_from_triangles(
+                ctx.handle if ctx else None, pos.ctypes.data, nrm.ctypes.data if nrm is not None else None,
+                tx.ctypes.data if tx is not None else None, nv, tri.ctypes.data, tri.shape[0], C.byref(h),
+            )
+        )
+        return cls(h, ctx)
+
+    def info(self) -> _lib.SceneInfo:
+        out = _lib.SceneInfo()
+        _lib.check(_lib.lib().mp_scene_info_get(self.handle, C.byref(out)))
+        return out
+
+    def get_bounding_box(self):
+        """Object::get_bounding_box (scene/mod.rs:9)."""
+        i = self.info()
+        return np.array(list(i.bbox_min), np.float32), np.array(list(i.bbox_max), np.float32)
+
+    def export(self):
+        """Reference-layout arrays: inner nodes (n,128) u8, packets (n,144) u8, tri shading (n*8,4) u32,
+        vertex normals / tex (nv,3) f32."""
+        i = self.info()
+        inner = np.zeros((i.inner_count, 128), np.uint8)
+        packets = np.zeros((i.packet_count, 144), np.uint8)
+        shading = np.zeros((i.packet_count * 8, 4), np.uint32)
+        vn = np.zeros((i.vertex_count, 3), np.float32)
+        vt = np.zeros((i.vertex_count, 3), np.float32)
+        _lib.check(
+            _lib.lib().mp_scene_export(
+                self.handle, inner.ctypes.data, packets.ctypes.data, shading.ctypes.data, vn.ctypes.data, vt.ctypes.data
+            )
+        )
+        return inner, packets, shading, vn, vt
+
+    def intersect(self, origins, directions, stream=None, full: bool = False):
+        """impl Object for TriangleBvh::intersect (ray_bvh_intersection.rs:26-96), batched over CUDA/HIP tensors.
+
+        origins, directions: float32 torch tensors [n,3] on this context's GPU (directions need not be unit).
+        Returns dict of device tensors: t, prim, u, v (+ point, normal, tex when full=True)."""
+        import torch
+
+        if self.ctx is None:
+            raise _lib.MinipathError(1, "host-only BVH cannot be traced: pass a Context to with_obj/build")
+        assert origins.is_cuda and directions.is_cuda and origins.dtype == torch.float32
+        n = origins.shape[0]
+        o = origins.t().contiguous()
+        d = directions.t().contiguous()
+        dev = origins.device
+        out = {
+            "t": torch.empty(n, dtype=torch.float32, device=dev),
+            "prim": torch.empty(n, dtype=torch.int32, device=dev),
+            "u": torch.empty(n, dtype=torch.float32, device=dev),
+            "v": torch.empty(n, dtype=torch.float32, device=dev),
+        }
+        hits = _lib.HitsSoA(out["t"].data_ptr(), out["prim"].data_ptr(), out["u"].data_ptr(), out["v"].data_ptr(), None, None, None)
+        if full:
+            for k in ("point", "normal", "tex"):
+                out[k] = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            hits.d_point, hits.d_normal, hits.d_tex = out["point"].data_ptr(), out["normal"].data_ptr(), out["tex"].data_ptr()
+        st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(
+            _lib.lib().mp_trace_rays(
+                self.ctx.handle, self.handle, o[0].data_ptr(), o[1].data_ptr(), o[2].data_ptr(), d[0].data_ptr(),
+                d[1].data_ptr(), d[2].data_ptr(), n, C.byref(hits), C.c_void_p(st),
+            )
+        )
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().mp_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scene:
+    """scene/mod.rs:12-15: Scene { object }."""
+
+    def __init__(self, object: TriangleBvh):
+        self.object = object

@@ -1,0 +1,95 @@
+"""CPU: the oracle (and the product's host builder) still reproduce the committed golden vectors."""
+import hashlib
+import os
+
+import numpy as np
+
+import minipath_amd as mp
+from tests.conftest import GOLDEN, TEAPOT
+
+
+def test_oracle_reproduces_golden(oracle, teapot_oracle_bvh):
+    g = np.load(os.path.join(GOLDEN, "teapot_golden.npz"))
+    b = teapot_oracle_bvh
+    assert list(g["bvh_counts"]) == [b.n_inner, b.n_packets, b.n_vertices, b.depth, b.root]
+    assert g["bvh_sha256"][0] == hashlib.sha256(b.inner_nodes_bytes().tobytes()).hexdigest()
+    assert g["bvh_sha256"][1] == hashlib.sha256(b.packets_bytes().tobytes()).hexdigest()
+    assert g["bvh_sha256"][2] == hashlib.sha256(b.tri_shading().tobytes()).hexdigest()
+    s = oracle.build_sampler(oracle.teapot_camera(), 256, 256)
+    assert np.array_equal(s.as_array().view(np.uint32), g["sampler"].view(np.uint32))
+    t, prim, u, v = b.trace(g["ray_o"], g["ray_d"])
+    assert np.array_equal(prim, g["hit_prim"]) and np.array_equal(t.view(np.uint32), g["hit_t_bits"])
+    f, u8 = b.render_tile(s, 256, 256, 16, int(g["seed"]), *[int(x) for x in g["tile"]])
+    assert np.array_equal(f.view(np.uint32), g["tile_f32_bits"]) and np.array_equal(u8, g["tile_u8"])
+
+
+def test_product_builder_reproduces_golden_digest():
+    g = np.load(os.path.join(GOLDEN, "teapot_golden.npz"))
+    inner, packets, shading, _, _ = mp.TriangleBvh.with_obj(TEAPOT).export()
+    assert g["bvh_sha256"][0] == hashlib.sha256(inner.tobytes()).hexdigest()
+    assert g["bvh_sha256"][1] == hashlib.sha256(packets.tobytes()).hexdigest()
+    assert g["bvh_sha256"][2] == hashlib.sha256(shading.tobytes()).hexdigest()
+
+
+def test_oracle_traversal_matches_brute_force(oracle, teapot_oracle_bvh):
+    """Self-check of the restated traversal (ray_bvh_intersection.rs:26-140), independent of BVH topology: the
+    closest hit over ALL decompressed triangles tested one by one (numpy f64 Moller-Trumbore on the oracle's own
+    quantised vertices) has the same t (to f32 rounding) and hits/misses agree away from silhouettes."""
+    b = teapot_oracle_bvh
+    g = np.load(os.path.join(GOLDEN, "teapot_golden.npz"))
+    o, d = g["ray_o"][:400].astype(np.float64), g["ray_d"][:400].astype(np.float64)
+    # decompress every packet against its leaf box by walking the tree with the oracle's box chain
+    inner = b.inner_nodes_bytes().view(np.uint8).reshape(-1, 128)
+    packets = b.packets_bytes().view(np.uint16).reshape(-1, 3, 3, 8)
+    inv = np.float32(1.0) / np.float32(65535.0)
+    tris = []
+
+    def dec(q, size, mn):
+        return (np.float32(size) * (q.astype(np.float32) * inv) + np.float32(mn)).astype(np.float32)
+
+    def walk(link, mn, mx):
+        size = (mx - mn).astype(np.float32)
+        if link == 0xFFFFFFF8:
+            return
+        idx, cnt = link >> 3, link & 7
+        if cnt == 0:
+            node = inner[idx]
+            u16 = node[:96].view(np.uint16).reshape(2, 3, 8)
+            links = node[96:].view(np.uint32)
+            for i in range(8):
+                cmn = np.array([dec(u16[0, k, i], size[k], mn[k]) for k in range(3)], np.float32)
+                cmx = np.array([dec(u16[1, k, i], size[k], mn[k]) for k in range(3)], np.float32)
+                walk(int(links[i]), cmn, cmx)
+        else:
+            for p in range(idx, idx + cnt):
+                for lane in range(8):
+                    v = np.array([[dec(packets[p, a, k, lane], size[k], mn[k]) for k in range(3)] for a in range(3)], np.float64)
+                    if not np.all(packets[p, :, :, lane] == 0):
+                        tris.append(v)
+
+    bmin, bmax = b.bbox()
+    walk(b.root, bmin, bmax)
+    T = np.array(tris)
+    assert len(T) >= 2256
+    v0, e1, e2 = T[:, 0], T[:, 1] - T[:, 0], T[:, 2] - T[:, 0]
+    t_oracle, prim, _, _ = b.trace(g["ray_o"][:400], g["ray_d"][:400])
+    agree = 0
+    for i in range(400):
+        dn = d[i] / np.linalg.norm(d[i])
+        h = np.cross(dn, e2)
+        det = np.einsum("ij,ij->i", e1, h)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            invd = 1.0 / det
+            s = o[i] - v0
+            u = invd * np.einsum("ij,ij->i", s, h)
+            q = np.cross(s, e1)
+            v = invd * (q @ dn)
+            t = invd * np.einsum("ij,ij->i", e2, q)
+        ok = (u >= 0) & (v >= 0) & (u + v <= 1) & (t >= 0)
+        tb = t[ok].min() if ok.any() else None
+        if tb is None:
+            agree += prim[i] == 0xFFFFFFFF
+        elif prim[i] != 0xFFFFFFFF:
+            assert abs(tb - t_oracle[i]) <= 2e-5 * max(1.0, tb), (i, tb, t_oracle[i])
+            agree += 1
+    assert agree >= 396  # silhouette rays may flip between f32 and f64

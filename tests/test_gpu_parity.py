@@ -1,0 +1,337 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against the CPU oracle
+on identical seeded inputs.  All comparisons are BIT-EXACT on f32 bit patterns (the north-star tolerance is 1e-5
+relative on the accumulated radiance; the implementation is written to meet it with zero difference) and exact on
+u8 / indices."""
+import threading
+
+import numpy as np
+import pytest
+
+import minipath_amd as mp
+from tests import meshes
+from tests.conftest import TEAPOT
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED
+REL_TOL = 1e-5  # BASELINE.json north_star: accumulated f32 radiance within 1e-5 relative
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return mp.Context(0)
+
+
+@pytest.fixture(scope="module")
+def teapot(ctx):
+    return mp.Scene(mp.TriangleBvh.with_obj(TEAPOT, ctx))
+
+
+def _trace_both(scene, orc, o, d, full=False):
+    import torch
+
+    to = torch.from_numpy(o).cuda()
+    td = torch.from_numpy(d).cuda()
+    out = scene.object.intersect(to, td, full=full)
+    torch.cuda.synchronize()
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    t, prim, u, v = orc.trace(o, d)
+    return got, (t, prim, u, v)
+
+
+def _assert_hits_equal(got, exp):
+    t, prim, u, v = exp
+    assert np.array_equal(got["prim"].view(np.uint32), prim), f"{int(np.sum(got['prim'].view(np.uint32) != prim))} prim mismatches"
+    assert np.array_equal(bits(got["t"]), bits(t))
+    hit = prim != 0xFFFFFFFF
+    assert np.array_equal(bits(got["u"])[hit], bits(u)[hit])
+    assert np.array_equal(bits(got["v"])[hit], bits(v)[hit])
+
+
+def test_trace_teapot_camera_rays_bit_exact(teapot, oracle, teapot_oracle_bvh):
+    """bit-identical (t, prim, u, v) on seeded teapot rays (K2+K3)."""
+    s = oracle.build_sampler(oracle.teapot_camera(), 256, 256)
+    rng = np.random.default_rng(1)
+    n = 60000
+    o = np.zeros((n, 3), np.float32)
+    d = np.zeros((n, 3), np.float32)
+    xs, ys = rng.integers(0, 256, n), rng.integers(0, 256, n)
+    for i in range(n):
+        r = oracle.sample_ray(s, int(xs[i]), int(ys[i]), 1000 + i)
+        o[i] = list(r.o)
+        d[i] = list(r.d)
+    got, exp = _trace_both(teapot, teapot_oracle_bvh, o, d)
+    _assert_hits_equal(got, exp)
+    assert 0.2 < np.mean(exp[1] != 0xFFFFFFFF) < 0.9
+
+
+def test_trace_random_rays_full_hit_record(teapot, oracle, teapot_oracle_bvh):
+    """Random origins incl. inside the model, axis-parallel and zero-component directions (inv = +inf path);
+    full HitRecord (point, normal, texture_coords) of ray_bvh_intersection.rs:66-95."""
+    bmin, bmax = teapot_oracle_bvh.bbox()
+    o, d = meshes.random_rays(20000, 7, bmin, bmax)
+    got, exp = _trace_both(teapot, teapot_oracle_bvh, o, d, full=True)
+    _assert_hits_equal(got, exp)
+    idx = np.nonzero(exp[1] != 0xFFFFFFFF)[0][:3000]
+    for i in idx:
+        h = teapot_oracle_bvh.intersect(oracle.ray_new(o[i], d[i]))
+        assert h.hit == 1
+        assert np.array_equal(bits(got["point"][i]), bits(np.array(list(h.point), np.float32)))
+        assert np.array_equal(bits(got["normal"][i]), bits(np.array(list(h.normal), np.float32)))
+        assert np.array_equal(bits(got["tex"][i]), bits(np.array(list(h.tex), np.float32)))
+
+
+@pytest.mark.parametrize("name", ["soup_300", "soup_5000", "grid_40", "sphere_24", "flat_plane", "two_clusters", "sliver_fan"])
+def test_trace_synthetic_scenes(ctx, oracle, name):
+    """Flat-shaded soups, smooth grids, degenerate (zero-extent) boxes, far-apart clusters, shared-edge ties."""
+    import torch
+
+    pos, nrm, tex, tri = meshes.make(name)
+    scene = mp.Scene(mp.TriangleBvh.build(pos, nrm, tex, tri, ctx))
+    orc = oracle.Bvh.build(pos, nrm, tex, tri)
+    bmin, bmax = orc.bbox()
+    o, d = meshes.random_rays(30000, 21, bmin, np.maximum(bmax, bmin + 1e-3))
+    got, exp = _trace_both(scene, orc, o, d, full=True)
+    _assert_hits_equal(got, exp)
+    idx = np.nonzero(exp[1] != 0xFFFFFFFF)[0][:500]
+    for i in idx:
+        h = orc.intersect(oracle.ray_new(o[i], d[i]))
+        assert np.array_equal(bits(got["normal"][i]), bits(np.array(list(h.normal), np.float32)))
+    if name not in ("flat_plane",):
+        assert len(idx) > 50
+    del scene
+    torch.cuda.synchronize()
+
+
+def test_trace_edge_sizes(teapot, teapot_oracle_bvh):
+    """n = 0, 1, 63, 64, 65 rays (partial wave queues)."""
+    import torch
+
+    bmin, bmax = teapot_oracle_bvh.bbox()
+    for n in (1, 63, 64, 65, 129):
+        o, d = meshes.random_rays(n, 100 + n, bmin, bmax)
+        got, exp = _trace_both(teapot, teapot_oracle_bvh, o, d)
+        _assert_hits_equal(got, exp)
+    out = teapot.object.intersect(torch.zeros((0, 3), device="cuda"), torch.zeros((0, 3), device="cuda"))
+    assert out["t"].numel() == 0
+
+
+def test_generate_rays_matches_sample_ray(ctx, oracle):
+    """K1: CameraSampler::sample_ray (camera.rs:176-191) in seeded mode, bit-exact."""
+    import ctypes as C
+
+    import torch
+
+    from minipath_amd import _lib
+
+    cam = mp.Camera.teapot_view()
+    st = mp.RenderSettings(64, 16, (256, 256), seed=SEED)
+    smp = cam.build_sampler(st.resolution)
+    blk = mp.ScreenBlock(40, 50, 72, 70)
+    n = blk.area()
+    bufs = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(6)]
+    s, ss = smp.as_struct(), st.as_struct()
+    for sample in (0, 5, 15):
+        _lib.check(
+            _lib.lib().mp_generate_rays(ctx.handle, C.byref(s), C.byref(ss), blk.as_struct(), sample, *[b.data_ptr() for b in bufs], None)
+        )
+        torch.cuda.synchronize()
+        g = [b.cpu().numpy() for b in bufs]
+        osmp = oracle.sampler_from_array(smp.as_array())
+        for i, (x, y) in enumerate(blk.internal_points()):
+            key = oracle.lib().mpo_sample_key(SEED, 256, 16, x, y, sample)
+            r = oracle.sample_ray(osmp, x, y, key)
+            exp = np.array(list(r.o) + list(r.d), np.float32)
+            assert np.array_equal(bits(np.array([g[k][i] for k in range(6)], np.float32)), bits(exp)), (x, y, sample)
+
+
+@pytest.mark.parametrize(
+    "res,tile_size,spp,tile",
+    [
+        ((256, 256), 64, 16, (64, 64, 128, 128)),     # SURVEY 8c golden: one 64x64 tile at 16 spp
+        ((256, 256), 64, 1, (128, 128, 192, 192)),    # spp = 1
+        ((250, 130), 64, 5, (192, 128, 250, 130)),    # clipped corner tile 58 x 2
+        ((256, 256), 20, 7, (100, 100, 120, 120)),    # tile size not a multiple of the 8x8 wave block
+        ((256, 256), 64, 3, (0, 0, 64, 64)),          # background-only tile
+    ],
+)
+def test_render_tile_bit_exact(teapot, oracle, teapot_oracle_bvh, res, tile_size, spp, tile):
+    """Worker::render_tile (worker.rs:32-49): f32 means bit-exact (<= 1e-5 rel required), u8 exact."""
+    cam = mp.Camera.teapot_view()
+    st = mp.RenderSettings(tile_size, spp, res, seed=SEED)
+    f, u8 = mp.render_tile(teapot, cam.build_sampler(res), st, mp.ScreenBlock(*tile))
+    of, ou8 = teapot_oracle_bvh.render_tile(oracle.build_sampler(oracle.teapot_camera(), *res), res[0], res[1], spp, SEED, *tile)
+    rel = np.abs(f - of) / np.maximum(np.abs(of), 1e-30)
+    assert rel.max() <= REL_TOL
+    assert np.array_equal(bits(f), bits(of)), f"{int(np.sum(bits(f) != bits(of)))} f32 values differ (max rel {rel.max()})"
+    assert np.array_equal(u8, ou8)
+
+
+def test_render_tile_empty_and_invalid(teapot):
+    cam = mp.Camera.teapot_view()
+    st = mp.RenderSettings(64, 2, (256, 256))
+    f, u8 = mp.render_tile(teapot, cam.build_sampler((256, 256)), st, mp.ScreenBlock(10, 10, 10, 30))
+    assert f.size == 0 and u8.size == 0
+    with pytest.raises(mp.MinipathError):  # tile larger than tile_size
+        mp.render_tile(teapot, cam.build_sampler((256, 256)), st, mp.ScreenBlock(0, 0, 65, 64))
+    with pytest.raises(mp.MinipathError):  # tile outside the resolution
+        mp.render_tile(teapot, cam.build_sampler((256, 256)), st, mp.ScreenBlock(224, 224, 288, 288))
+
+
+def test_c1_frame_matches_oracle(teapot, oracle, teapot_oracle_bvh):
+    """BASELINE config C1 (teapot 256x256, 16 spp): the whole frame through the one-launch device path + untile,
+    against the oracle's threaded render (machinery.rs semantics): f32 bit-exact, u8 exact."""
+    import torch
+
+    cam = mp.Camera.teapot_view()
+    st = mp.RenderSettings(64, 16, (256, 256), seed=SEED)
+    fr = mp.FrameRenderer(teapot, cam, st)
+    fr.render()
+    img, img8 = fr.untile()
+    torch.cuda.synchronize()
+    of, ou8, _, rays, _ = teapot_oracle_bvh.render_image_mt(oracle.build_sampler(oracle.teapot_camera(), 256, 256), 256, 256, 16, SEED, 64, 8)
+    assert rays == 256 * 256 * 16 == fr.rays_per_frame
+    assert np.array_equal(bits(img.cpu().numpy()), bits(of))
+    assert np.array_equal(img8.cpu().numpy(), ou8)
+    cover = (of[..., 3] > 0).mean()
+    assert 0.3 < cover < 0.7
+
+
+def test_render_async_api(teapot, oracle, teapot_oracle_bvh):
+    """render()/RenderProgress (machinery.rs:20-178): callbacks once per tile start/end, progress, image, elapsed."""
+    cam = mp.Camera.teapot_view()
+    st = mp.RenderSettings(32, 4, (160, 96), seed=SEED)
+    started, finished, lock = [], [], threading.Lock()
+
+    def on_start(t):
+        with lock:
+            started.append(t)
+
+    def on_finish(t, snap):
+        with lock:
+            finished.append((t, snap.finished, snap.total))
+
+    rp = mp.render(teapot, cam, st, on_start, on_finish)
+    rp.wait()
+    assert rp.is_finished()
+    tiles = mp.tile_ordering(mp.ScreenBlock(0, 0, 160, 96), 32)
+    assert len(tiles) == 15
+    assert sorted(t.as_struct().as_tuple() for t in started) == sorted(t.as_struct().as_tuple() for t in tiles)
+    assert sorted(t.as_struct().as_tuple() for t, _, _ in finished) == sorted(t.as_struct().as_tuple() for t in tiles)
+    assert sorted(f for _, f, _ in finished) == list(range(1, 16)) and all(tot == 15 for _, _, tot in finished)
+    p = rp.progress()
+    assert (p.finished, p.total) == (15, 15) and p.percent() == 100.0
+    e1 = rp.elapsed()
+    assert e1 > 0 and rp.elapsed() == e1  # stops incrementing once finished (machinery.rs:148-157)
+    of, ou8, *_ = teapot_oracle_bvh.render_image_mt(oracle.build_sampler(oracle.teapot_camera(), 160, 96), 160, 96, 4, SEED, 32, 4)
+    assert np.array_equal(rp.image(), ou8)
+    assert np.array_equal(bits(rp.image_f32()), bits(of))
+    # shuffled tile order renders the same image
+    rp2 = mp.render(teapot, cam, mp.RenderSettings(32, 4, (160, 96), seed=SEED, shuffle_tiles=True))
+    rp2.wait()
+    assert np.array_equal(rp2.image(), ou8)
+
+
+def test_render_abort(teapot):
+    """RenderProgress::abort (machinery.rs:159-165): in-flight tiles finish, no new ones start."""
+    cam = mp.Camera.teapot_view()
+    st = mp.RenderSettings(8, 64, (1024, 1024), seed=1)  # 16384 tiles, many batches
+    rp = mp.render(teapot, cam, st)
+    rp.abort()
+    rp.wait()
+    p = rp.progress()
+    assert rp.is_finished() and p.finished < p.total
+    img = rp.image()
+    assert img.shape == (1024, 1024, 4)
+
+
+def test_untile_color_to_image(ctx, teapot, oracle):
+    """K7 + color_to_image (worker.rs:69-76) on the device incl. rounding ties, clamps and NaN."""
+    import ctypes as C
+
+    import torch
+
+    from minipath_amd import _lib
+
+    st = mp.RenderSettings(4, 1, (8, 4))
+    tiles = mp.tile_ordering(mp.ScreenBlock(0, 0, 8, 4), 4)
+    vals = np.array([0.5 / 255, 1.5 / 255, 2.5 / 255, 0.49999 / 255, 1.0, 2.0, -1.0, np.nan, 254.5 / 255, 0.0, 0.999, 127.5 / 255], np.float32)
+    buf = np.resize(vals, (2, 4, 4, 4)).astype(np.float32)
+    d = torch.from_numpy(buf).cuda()
+    img = torch.zeros((4, 8, 4), dtype=torch.float32, device="cuda")
+    img8 = torch.zeros((4, 8, 4), dtype=torch.uint8, device="cuda")
+    tc = (_lib.Block * 2)(*[t.as_struct() for t in tiles])
+    ss = st.as_struct()
+    _lib.check(_lib.lib().mp_untile(ctx.handle, C.byref(ss), tc, 2, d.data_ptr(), img.data_ptr(), img8.data_ptr(), None))
+    torch.cuda.synchronize()
+    exp = np.concatenate([buf[0], buf[1]], axis=1)
+    assert np.array_equal(bits(img.cpu().numpy()), bits(exp))
+    out = np.zeros(4, np.uint8)
+    e8 = np.zeros((4, 8, 4), np.uint8)
+    for y in range(4):
+        for x in range(8):
+            oracle.lib().mpo_color_to_image(exp[y, x].ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+            e8[y, x] = out
+    assert np.array_equal(img8.cpu().numpy(), e8)
+
+
+def test_full_size_properties(teapot):
+    """BASELINE config C2 geometry (teapot 1920x1080, tile 64) at reduced spp: size-independent properties.
+    idempotence (two launches give identical bits); any subset of tiles reproduces the same pixels (tiles are
+    independent units); alpha = hits/spp is a multiple of 1/spp in [0,1]; grey <= alpha."""
+    import torch
+
+    cam = mp.Camera.teapot_view()
+    spp = 8
+    st = mp.RenderSettings(64, spp, (1920, 1080), seed=SEED)
+    fr = mp.FrameRenderer(teapot, cam, st)
+    assert len(fr.tiles) == 510 and fr.rays_per_frame == 1920 * 1080 * spp
+    a = fr.render().clone()
+    b = fr.render().clone()
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    img, img8 = fr.untile()
+    sub = fr.tiles[3::7]
+    fr2 = mp.FrameRenderer(teapot, cam, st, tiles=sub)
+    fr2.render()
+    img2, _ = fr2.untile()
+    torch.cuda.synchronize()
+    img, img2 = img.cpu().numpy(), img2.cpu().numpy()
+    for t in sub:
+        assert np.array_equal(bits(img[t.min_y:t.max_y, t.min_x:t.max_x]), bits(img2[t.min_y:t.max_y, t.min_x:t.max_x]))
+    alpha = img[..., 3]
+    assert alpha.min() >= 0 and alpha.max() <= 1 and np.allclose(alpha * spp, np.round(alpha * spp), atol=1e-5)
+    assert np.all(img[..., 0] <= alpha + 1e-6) and np.array_equal(img[..., 0], img[..., 1]) and np.array_equal(img[..., 0], img[..., 2])
+    assert 0.05 < (alpha > 0).mean() < 0.6
+    i8 = img8.cpu().numpy()
+    assert np.array_equal(i8[..., 3] == 0, alpha < 0.5 / 255)
+
+
+def test_golden_fixtures(teapot, ctx):
+    """tests/golden/teapot_golden.npz (made by tests/golden/make_golden.py from the oracle): 4096 seeded rays and
+    one 64x64 tile at 16 spp."""
+    import os
+
+    import torch
+
+    from tests.conftest import GOLDEN
+
+    g = np.load(os.path.join(GOLDEN, "teapot_golden.npz"))
+    out = teapot.object.intersect(torch.from_numpy(g["ray_o"]).cuda(), torch.from_numpy(g["ray_d"]).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(out["prim"].cpu().numpy().view(np.uint32), g["hit_prim"])
+    assert np.array_equal(bits(out["t"].cpu().numpy()), g["hit_t_bits"])
+    hit = g["hit_prim"] != 0xFFFFFFFF
+    assert np.array_equal(bits(out["u"].cpu().numpy())[hit], g["hit_u_bits"][hit])
+    assert np.array_equal(bits(out["v"].cpu().numpy())[hit], g["hit_v_bits"][hit])
+    st = mp.RenderSettings(64, 16, (256, 256), seed=int(g["seed"]))
+    f, u8 = mp.render_tile(teapot, mp.Camera.teapot_view().build_sampler((256, 256)), st, mp.ScreenBlock(*[int(v) for v in g["tile"]]))
+    assert np.array_equal(bits(f), g["tile_f32_bits"])
+    assert np.array_equal(u8, g["tile_u8"])

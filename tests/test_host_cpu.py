@@ -1,0 +1,218 @@
+"""CPU-only tests of the product's host side (no GPU, no compute calls): the C-ABI library loads and exports every
+symbol include/minipath_hip.h declares; the C++ BVH builder / camera / tile code of libminipath_hip.so produces
+byte-identical data to the oracle's independent C restatement."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import minipath_amd as mp
+from minipath_amd import _lib
+from tests.conftest import ROOT, TEAPOT
+from tests import meshes
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "minipath_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mp_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"mp_tile_started_cb", "mp_tile_finished_cb"}
+    assert len(declared) >= 30
+    L = C.CDLL(_lib.SO_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/minipath_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert b"gfx950" in _lib.lib().mp_version()
+
+
+def _assert_same_bvh(prod: mp.TriangleBvh, orc):
+    i = prod.info()
+    assert (i.inner_count, i.packet_count, i.vertex_count, i.depth) == (orc.n_inner, orc.n_packets, orc.n_vertices, orc.depth)
+    assert i.root_link == orc.root
+    bmin, bmax = orc.bbox()
+    assert np.array_equal(np.array(list(i.bbox_min), np.float32), bmin)
+    assert np.array_equal(np.array(list(i.bbox_max), np.float32), bmax)
+    inner, packets, shading, vn, vt = prod.export()
+    assert np.array_equal(inner.reshape(-1), orc.inner_nodes_bytes())
+    assert np.array_equal(packets.reshape(-1), orc.packets_bytes())
+    assert np.array_equal(shading, orc.tri_shading())
+    assert np.array_equal(vn.view(np.uint32), orc.vertex_normals().view(np.uint32))
+    assert np.array_equal(vt.view(np.uint32), orc.vertex_tex().view(np.uint32))
+
+
+def test_builder_teapot_matches_oracle(oracle, teapot_oracle_bvh):
+    """building.rs (all): OBJ load + dedupe + recursive build, byte-identical reference-layout arrays."""
+    prod = mp.TriangleBvh.with_obj(TEAPOT)
+    _assert_same_bvh(prod, teapot_oracle_bvh)
+    i = prod.info()
+    assert i.triangle_count == 2256 and i.vertex_count == 1202
+    assert np.allclose(list(i.bbox_min), [-3, 0, -2]) and np.allclose(list(i.bbox_max), [3.42963, 3.15, 2])
+
+
+@pytest.mark.parametrize("name", ["soup_300", "soup_5000", "grid_40", "sphere_24", "flat_plane", "two_clusters", "sliver_fan"])
+def test_builder_synthetic_meshes_match_oracle(oracle, name):
+    pos, nrm, tex, tri = meshes.make(name)
+    prod = mp.TriangleBvh.build(pos, nrm, tex, tri)
+    orc = oracle.Bvh.build(pos, nrm, tex, tri)
+    _assert_same_bvh(prod, orc)
+
+
+def test_builder_unbuildable_planar_mesh(oracle):
+    """An axis-aligned planar mesh above the leaf size has a zero-volume centroid box: the reference's BinGrid
+    (building.rs:424-429) panics; product and oracle both report MP_ERR_BUILD."""
+    pos, nrm, tex, tri = meshes.make("flat_plane_big")
+    with pytest.raises(mp.MinipathError) as e:
+        mp.TriangleBvh.build(pos, nrm, tex, tri)
+    assert e.value.code == 3
+    with pytest.raises(RuntimeError):
+        oracle.Bvh.build(pos, nrm, tex, tri)
+
+
+def test_builder_invariants(teapot_oracle_bvh):
+    """Builder self-checks: every input triangle appears exactly once; quantised vertices are within
+    one u16 step of the true position; leaf links have 1..7 packets."""
+    prod = mp.TriangleBvh.with_obj(TEAPOT)
+    inner, packets, shading, vn, vt = prod.export()
+    info = prod.info()
+    links = inner.view(np.uint32).reshape(-1, 32)[:, 24:]
+    leaf = links[(links != 0xFFFFFFF8) & ((links & 7) != 0)]
+    assert leaf.size > 0 and np.all((leaf & 7) >= 1)
+    assert int(np.sum(leaf & 7)) == info.packet_count
+    # first packets of leaves partition [0, packet_count)
+    starts = np.sort(leaf >> 3)
+    assert starts[0] == 0 and len(np.unique(starts)) == len(starts)
+    # real triangles: shading rows that are not all-zero padding (vertex 0,0,0 is never a real teapot triangle)
+    real = shading[~np.all(shading[:, :3] == 0, axis=1)]
+    assert real.shape[0] == info.triangle_count
+
+
+def test_obj_errors_mirror_reference_panics(tmp_path):
+    """building.rs:209-216 ObjOpenError; :43-46 non-triangles skipped then :178 assert (data/cube.obj case)."""
+    with pytest.raises(mp.MinipathError) as e:
+        mp.TriangleBvh.with_obj(str(tmp_path / "missing.obj"))
+    assert e.value.code == 2 and "Failed to read file" in e.value.message
+    cube = tmp_path / "cube.obj"
+    cube.write_text("v -0.5 -0.5 -0.5\nv 0.5 -0.5 -0.5\nv 0.5 0.5 -0.5\nv -0.5 0.5 -0.5\nf 1 2 3 4\n")
+    with pytest.raises(mp.MinipathError) as e:
+        mp.TriangleBvh.with_obj(str(cube))
+    assert e.value.code == 3  # MP_ERR_BUILD: the reference panics here
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 9\n")
+    with pytest.raises(mp.MinipathError) as e:
+        mp.TriangleBvh.with_obj(str(bad))
+    assert e.value.code == 2
+    with pytest.raises(mp.MinipathError):
+        mp.TriangleBvh.build(np.zeros((3, 3), np.float32), None, None, np.array([[0, 1, 7]], np.uint32))
+
+
+def test_obj_features(tmp_path, oracle):
+    """v/vt/vn index forms, negative indices, mixed polygons, vertex dedupe in first-seen order (building.rs:48-67)."""
+    p = tmp_path / "m.obj"
+    p.write_text(
+        "o a\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0.5\nvt 0 0\nvt 1 0\nvt 0 1\nvn 0 0 2\n"
+        "g g1\nf 1/1/1 2/2/1 3/3/1\nf 1 2 3 4\ng g2\nf -3//1 -2//1 -1//1\nf 2/2 4/3 3/1\n"
+    )
+    prod = mp.TriangleBvh.with_obj(str(p))
+    orc = oracle.Bvh.from_obj(str(p))
+    _assert_same_bvh(prod, orc)
+    i = prod.info()
+    assert i.triangle_count == 3 and i.vertex_count == 9
+    _, _, shading, vn, vt = prod.export()
+    assert np.allclose(vn[0], [0, 0, 1])  # normalised at load (building.rs:60-63)
+    assert np.allclose(vt[1], [1, 0, 0])
+    assert list(shading[:3, 3]) == [0, 0, 1]  # third triangle has no normals -> flat
+
+
+def test_camera_matches_oracle_bitwise(oracle):
+    """camera.rs:93-171: look_at / look_direction / build_sampler, product C++ vs oracle C."""
+    cams = [
+        (mp.Camera.teapot_view(), oracle.teapot_camera()),
+    ]
+    c2 = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(c2))
+    oracle.lib().mpo_camera_look_direction(C.byref(c2), oracle.vec3(1, -2, 0.5), oracle.vec3(0.3, 1, -0.2), oracle.vec3(0, 0, 1))
+    c2.focus_distance = 2.0
+    cams.append((mp.Camera.default().look_direction((1, -2, 0.5), (0.3, 1, -0.2), (0, 0, 1)).focus_distance(2.0), c2))
+    c3 = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(c3))
+    oracle.lib().mpo_camera_look_at(C.byref(c3), oracle.vec3(-4, 3, -6), oracle.vec3(0.5, 0, 1), oracle.vec3(0, 1, 0))
+    c3.sensor_is_width = 1
+    c3.sensor_size = 36e-3
+    cams.append((mp.Camera.default().look_at((-4, 3, -6), (0.5, 0, 1), (0, 1, 0)).sensor_width(36e-3), c3))
+    for res in [(256, 256), (1920, 1080), (800, 600)]:
+        for pc, oc in cams:
+            a = pc.build_sampler(res).as_array()
+            b = oracle.build_sampler(oc, *res).as_array()
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (res, a, b)
+
+
+def test_camera_reference_tests():
+    """camera.rs:201-247 on the product's host code."""
+    cam = mp.Camera.default().look_direction((0, 0, 0), (0, 1, 0), (0, 0, 1)).focus_distance(2.0)
+    center, fwd, up, right = cam.center_forward_up_right()
+    assert np.allclose(fwd, [0, 1, 0], atol=1e-6) and np.allclose(up, [0, 0, 1], atol=1e-6) and np.allclose(right, [1, 0, 0], atol=1e-6)
+    moved = cam.translated((1.0, 2.0, 3.0))
+    assert np.linalg.norm(moved.center_forward_up_right()[0] - np.array([1, 2, 3], np.float32)) < 1e-6
+    assert mp.Camera.default().focus_distance_ == float("inf") and mp.Camera.default().f_number_ == 9.0
+    s = mp.Camera.default().build_sampler((800, 600)).as_array()
+    assert s[14] == 0.0  # infinite focus => lens_weight 0 (camera.rs:144)
+
+
+def test_tile_ordering_matches_oracle_and_covers(oracle):
+    """screen_block.rs:46-81,144-160 and its tests :228-240."""
+    rng = np.random.default_rng(9)
+    cases = [((0, 0, 1920, 1080), 64), ((0, 0, 1, 86), 1), ((0, 0, 0, 0), 4), ((3, 5, 3, 9), 2), ((0, 0, 256, 256), 64)]
+    for _ in range(40):
+        x, y, w, h = (int(v) for v in (rng.integers(0, 1000), rng.integers(0, 1000), rng.integers(0, 20), rng.integers(0, 20)))
+        cases.append(((x, y, x + w, y + h), int(rng.integers(1, 10))))
+    for blk, ts in cases:
+        got = mp.tile_ordering(mp.ScreenBlock(*blk), ts)
+        exp = oracle.tile_ordering(*blk, ts)
+        assert [t.as_struct().as_tuple() for t in got] == [tuple(int(v) for v in r) for r in exp]
+        sh = mp.tile_ordering(mp.ScreenBlock(*blk), ts, shuffle_seed=1234)
+        assert sorted(t.as_struct().as_tuple() for t in sh) == sorted(t.as_struct().as_tuple() for t in got)
+        seen = set()
+        for t in got:
+            for p in t.internal_points():
+                assert p not in seen and mp.ScreenBlock(*blk).contains(*p)
+                seen.add(p)
+        assert len(seen) == mp.ScreenBlock(*blk).area()
+    assert len(mp.tile_ordering(mp.ScreenBlock(0, 0, 1920, 1080), 64)) == 510  # C2 = 510 tiles
+    with pytest.raises(ValueError):
+        mp.tile_ordering(mp.ScreenBlock(0, 0, 4, 4), 0)
+
+
+def test_shuffled_tile_order_is_centre_out_on_average():
+    blk = mp.ScreenBlock(0, 0, 1024, 1024)
+    tiles = mp.tile_ordering(blk, 64, shuffle_seed=99)
+    d = [np.hypot((t.min_x + t.max_x) / 2 - 512, (t.min_y + t.max_y) / 2 - 512) for t in tiles]
+    assert np.mean(d[:32]) < np.mean(d[-32:])
+
+
+def test_screen_block_basics():
+    """screen_block.rs:243-254."""
+    assert not mp.ScreenBlock(0, 0, 10, 10).is_empty()
+    assert mp.ScreenBlock(0, 0, 0, 0).is_empty() and mp.ScreenBlock(0, 0, 10, 0).is_empty() and mp.ScreenBlock(5, 5, 10, 1).is_empty()
+    assert mp.ScreenBlock(0, 0, 1, 1).area() == 1 and mp.ScreenBlock(5, 5, 10, 1).area() == 0
+
+
+def test_host_only_scene_cannot_render():
+    bvh = mp.TriangleBvh.with_obj(TEAPOT)
+    scene = mp.Scene(bvh)
+    st = mp.RenderSettings(64, 1, (64, 64))
+    with pytest.raises(mp.MinipathError):
+        mp.render(scene, mp.Camera.teapot_view(), st)
+    with pytest.raises(mp.MinipathError):
+        mp.render_tile(scene, mp.Camera.teapot_view().build_sampler((64, 64)), st, mp.ScreenBlock(0, 0, 64, 64))
+
+
+def test_product_does_not_import_oracle():
+    """The product path must never route through the oracle."""
+    pkg = os.path.join(ROOT, "minipath_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "minipath_oracle" not in txt and "liboracle" not in txt, f
