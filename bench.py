@@ -109,10 +109,10 @@ def main():
         gather_tiles += tl + [mp.ScreenBlock(0, 0, 0, 0)] * (per_rank - len(tl))
     full_fr = mp.FrameRenderer(scene, cam, st, tiles=all_tiles[:1]) if rank == 0 else None  # untile helper only
     total_rays = args.width * args.height * args.spp
-    kernel_ms = []
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    events = []
 
     def step(timed):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         buf = fr.render()
         ev1.record()
@@ -125,8 +125,7 @@ def main():
         else:
             img, _ = fr.untile(want_u8=True)
         if timed:
-            torch.cuda.synchronize(dev)
-            kernel_ms.append(ev0.elapsed_time(ev1))
+            events.append((ev0, ev1))
         return img
 
     def untile_gathered():
@@ -151,6 +150,7 @@ def main():
         img = step(True)
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in events]
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
