@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "teapot.obj"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tile-stride", type=int, default=16, help="cpu_baseline renders every k-th tile")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on cpu_baseline worker threads")
     ap.add_argument("--check", action="store_true", help="compare a few tiles of the GPU frame with the oracle")
     return ap.parse_args()
 
@@ -55,6 +56,8 @@ def cpu_baseline(args):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # a one-GPU box's CPU share is 16 cores however many the host exposes; `cores` = the threads actually used
+    cores = min(cores, args.cpu_threads)
     b = po.Bvh.from_obj(args.scene)
     s = po.build_sampler(po.teapot_camera(), args.width, args.height)
     ntiles = len(po.tile_ordering(0, 0, args.width, args.height, args.tile))
