@@ -81,6 +81,7 @@ typedef struct {
 } mp_settings;
 
 #define MP_FLAG_SHUFFLE_TILES 1u /* centre-out tile order with random noise (screen_block.rs:74-78); default: row-major */
+#define MP_FLAG_TRAVERSAL_GROUPS 2u /* camera rays on the 8-lane-group traversal instead of 64-ray packets (same results) */
 
 /* machinery.rs:180-189 RenderProgressSnapshot */
 typedef struct { size_t finished, total; } mp_progress;

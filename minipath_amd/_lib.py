@@ -15,6 +15,7 @@ MP_OK = 0
 MP_NO_PRIM = 0xFFFFFFFF
 MP_LINK_NULL = 0xFFFFFFF8
 MP_FLAG_SHUFFLE_TILES = 1
+MP_FLAG_TRAVERSAL_GROUPS = 2
 
 
 class MinipathError(RuntimeError):

@@ -68,6 +68,9 @@ struct mp_scene {
     void* d_shade = nullptr;
     void* d_vidx = nullptr;
     void* d_vtex = nullptr;
+    void* d_nodes_aos = nullptr;
+    void* d_tris_aos = nullptr;
+    void* d_pkt_valid = nullptr;
     uint64_t device_bytes = 0;
 };
 
@@ -129,6 +132,27 @@ int upload_scene(mp_scene* s) {
             std::memcpy(&so[9], &flat, 4);
         }
     }
+    // AoS copies for the scalar-unit fetch of the ray-packet traversal (same values, different order)
+    std::vector<float> nodes_aos(std::max<size_t>(ni, 1) * 64, 0.0f);
+    for (size_t n = 0; n < ni; n++)
+        for (int i = 0; i < 8; i++) {
+            for (int k = 0; k < 6; k++) nodes_aos[n * 64 + i * 8 + k] = nodes[n * kNodeDwords + k * 8 + i];
+            nodes_aos[n * 64 + i * 8 + 6] = nodes[n * kNodeDwords + 48 + i];
+        }
+    std::vector<float> tris_aos(np * 96, 0.0f);
+    std::vector<uint32_t> pkt_valid(np, 0);
+    for (size_t p = 0; p < np; p++)
+        for (int i = 0; i < 8; i++) {
+            for (int k = 0; k < 9; k++) tris_aos[p * 96 + i * 12 + k] = tris[p * kPacketDwords + k * 8 + i];
+            // padding lanes are all-zero quantised triangles with default shading, at the tail of a leaf's last packet
+            bool pad = true;
+            for (int a = 0; a < 3 && pad; a++)
+                for (int k = 0; k < 3; k++)
+                    if (h.packets[p].v[a][k][i] != 0) { pad = false; break; }
+            const TriShadingRef& sh = h.shading[p * 8 + i];
+            pad = pad && sh.vi[0] == 0 && sh.vi[1] == 0 && sh.vi[2] == 0 && sh.flat == 0;
+            if (!pad) pkt_valid[p] = static_cast<uint32_t>(i + 1);
+        }
     auto up = [&](void** dst, const void* src, size_t bytes) -> int {
         bytes = std::max<size_t>(bytes, 16);
         MP_HIP(hipMalloc(dst, bytes));
@@ -142,6 +166,12 @@ int upload_scene(mp_scene* s) {
     if ((rc = up(&s->d_shade, shade.data(), shade.size() * 4))) return rc;
     if ((rc = up(&s->d_vidx, vidx.data(), vidx.size() * 4))) return rc;
     if ((rc = up(&s->d_vtex, h.vtex.data(), h.vtex.size() * 4))) return rc;
+    if ((rc = up(&s->d_nodes_aos, nodes_aos.data(), nodes_aos.size() * 4))) return rc;
+    if ((rc = up(&s->d_tris_aos, tris_aos.data(), tris_aos.size() * 4))) return rc;
+    if ((rc = up(&s->d_pkt_valid, pkt_valid.data(), pkt_valid.size() * 4))) return rc;
+    MP_HIP(hipMemcpy(s->d_nodes_aos, nodes_aos.data(), nodes_aos.size() * 4, hipMemcpyHostToDevice));
+    if (!tris_aos.empty()) MP_HIP(hipMemcpy(s->d_tris_aos, tris_aos.data(), tris_aos.size() * 4, hipMemcpyHostToDevice));
+    if (!pkt_valid.empty()) MP_HIP(hipMemcpy(s->d_pkt_valid, pkt_valid.data(), pkt_valid.size() * 4, hipMemcpyHostToDevice));
     MP_HIP(hipMemcpy(s->d_nodes, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice));
     if (!tris.empty()) MP_HIP(hipMemcpy(s->d_tris, tris.data(), tris.size() * 4, hipMemcpyHostToDevice));
     if (!shade.empty()) MP_HIP(hipMemcpy(s->d_shade, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
@@ -152,10 +182,28 @@ int upload_scene(mp_scene* s) {
     s->dev.shade = static_cast<const float*>(s->d_shade);
     s->dev.vidx = static_cast<const uint32_t*>(s->d_vidx);
     s->dev.vtex = static_cast<const float*>(s->d_vtex);
+    s->dev.nodes_aos = static_cast<const float*>(s->d_nodes_aos);
+    s->dev.tris_aos = static_cast<const float*>(s->d_tris_aos);
+    s->dev.pkt_valid = static_cast<const uint32_t*>(s->d_pkt_valid);
     s->dev.root = h.root;
     s->dev.inner_count = static_cast<uint32_t>(ni);
     s->dev.packet_count = static_cast<uint32_t>(np);
     s->dev.stack_cap = 7 * h.depth + 1;
+    s->dev.has_pre = 0;
+    if ((h.root & 7u) == 0u && h.root != MP_LINK_NULL) {  // root is an inner node
+        const float* o = &nodes[static_cast<size_t>(h.root >> 3) * kNodeDwords];
+        bool any = false;
+        for (int i = 0; i < 8; i++) {
+            if (h.inner[h.root >> 3].link[i] == MP_LINK_NULL) continue;
+            for (int k = 0; k < 3; k++) {
+                float mn = o[k * 8 + i], mx = o[(3 + k) * 8 + i];
+                s->dev.pre_min[k] = any ? std::fmin(s->dev.pre_min[k], mn) : mn;
+                s->dev.pre_max[k] = any ? std::fmax(s->dev.pre_max[k], mx) : mx;
+            }
+            any = true;
+        }
+        s->dev.has_pre = any ? 1u : 0u;
+    }
     return MP_OK;
 }
 
@@ -196,6 +244,7 @@ int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_samp
     L.d_out = d_out;
     L.d_counter = ctx->take_counter();
     L.cu_count = ctx->cu_count;
+    L.traversal = (st.flags & MP_FLAG_TRAVERSAL_GROUPS) ? 1 : 0;
     std::string err;
     int rc = launch_render_tiles(L, stream, err);
     if (rc) return fail(rc, err);
@@ -312,7 +361,7 @@ void mp_scene_destroy(mp_scene* s) {
     if (!s) return;
     if (s->ctx) {
         DeviceGuard g(s->ctx->device);
-        for (void* p : {s->d_nodes, s->d_tris, s->d_shade, s->d_vidx, s->d_vtex})
+        for (void* p : {s->d_nodes, s->d_tris, s->d_shade, s->d_vidx, s->d_vtex, s->d_nodes_aos, s->d_tris_aos, s->d_pkt_valid})
             if (p) (void)hipFree(p);
     }
     delete s;

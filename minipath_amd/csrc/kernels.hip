@@ -14,6 +14,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 #include "mp_internal.h"
 
@@ -157,6 +158,13 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
     int slot = -1, sp = 0, head = 0;
     uint32_t pk = 0, pk_end = 0, seq = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0;
+    // Slab planes by ray sign: with a finite inverse direction, min/max of the two plane distances of an axis is
+    // decided by the sign alone ((bmin-o)*inv <= (bmax-o)*inv for inv > 0 by monotonicity of IEEE rounding, reversed
+    // for inv < 0), and no NaN can arise (0 * finite), so aabb.rs:262-271 reduces to reading the near / far plane
+    // row directly.  Rays with an infinite inverse component (direction component 0 or subnormal) take the literal
+    // path below.
+    int near_x = 0, near_y = 8, near_z = 16, far_x = 24, far_y = 32, far_z = 40;
+    bool slow = false;
     float best_t = FLT_MAX;                 // best.t, group-uniform (ray_bvh_intersection.rs:34-37)
     float tl = FLT_MAX, ul = 0, vl = 0;     // this lane's earliest closest candidate
     uint32_t pkl = kNoPrim, seql = 0;
@@ -193,6 +201,10 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
                 ox = q[0 * 64 + mine]; oy = q[1 * 64 + mine]; oz = q[2 * 64 + mine];
                 dx = q[3 * 64 + mine]; dy = q[4 * 64 + mine]; dz = q[5 * 64 + mine];
                 ix = q[6 * 64 + mine]; iy = q[7 * 64 + mine]; iz = q[8 * 64 + mine];
+                near_x = ix < 0.0f ? 24 : 0; far_x = 24 - near_x;
+                near_y = iy < 0.0f ? 32 : 8; far_y = 40 - near_y;
+                near_z = iz < 0.0f ? 40 : 16; far_z = 56 - near_z;
+                slow = fabsf(ix) == INFINITY || fabsf(iy) == INFINITY || fabsf(iz) == INFINITY;
                 best_t = FLT_MAX; tl = FLT_MAX; ul = 0; vl = 0; pkl = kNoPrim; seql = 0; seq = 0;
                 pk = pk_end = 0;
                 sp = 1;
@@ -212,17 +224,25 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
                     // InnerNode::intersect :149-162 ; lane li = child li.  Child boxes are stored decompressed
                     // (SURVEY A.4 box chain evaluated once on the host), so the slab test starts directly.
                     const float* nd = sc.nodes + static_cast<size_t>(link >> 3) * kNodeDwords + li;
-                    float bnx = nd[0], bny = nd[8], bnz = nd[16], bxx = nd[24], bxy = nd[32], bxz = nd[40];
                     uint32_t child = as_u(nd[48]);
-                    // aabb.rs:254-284
-                    float ax = (bnx - ox) * ix, ay = (bny - oy) * iy, az = (bnz - oz) * iz;
-                    float cx = (bxx - ox) * ix, cy = (bxy - oy) * iy, cz = (bxz - oz) * iz;
-                    ax = (ax != ax) ? -INFINITY : ax; ay = (ay != ay) ? -INFINITY : ay; az = (az != az) ? -INFINITY : az;
-                    cx = (cx != cx) ? INFINITY : cx; cy = (cy != cy) ? INFINITY : cy; cz = (cz != cz) ? INFINITY : cz;
-                    float lox = fminf(ax, cx), loy = fminf(ay, cy), loz = fminf(az, cz);
-                    float hix = fmaxf(ax, cx), hiy = fmaxf(ay, cy), hiz = fmaxf(az, cz);
-                    float t1 = fmaxf(fmaxf(lox, 0.0f), fmaxf(loy, loz));
-                    float t2 = fminf(fminf(hix, best_t), fminf(hiy, hiz));
+                    float t1, t2;
+                    if (__ballot(slow) == 0) {
+                        float lox = (nd[near_x] - ox) * ix, loy = (nd[near_y] - oy) * iy, loz = (nd[near_z] - oz) * iz;
+                        float hix = (nd[far_x] - ox) * ix, hiy = (nd[far_y] - oy) * iy, hiz = (nd[far_z] - oz) * iz;
+                        t1 = fmaxf(fmaxf(lox, 0.0f), fmaxf(loy, loz));
+                        t2 = fminf(fminf(hix, best_t), fminf(hiy, hiz));
+                    } else {
+                        // aabb.rs:254-284, literal
+                        float bnx = nd[0], bny = nd[8], bnz = nd[16], bxx = nd[24], bxy = nd[32], bxz = nd[40];
+                        float ax = (bnx - ox) * ix, ay = (bny - oy) * iy, az = (bnz - oz) * iz;
+                        float cx = (bxx - ox) * ix, cy = (bxy - oy) * iy, cz = (bxz - oz) * iz;
+                        ax = (ax != ax) ? -INFINITY : ax; ay = (ay != ay) ? -INFINITY : ay; az = (az != az) ? -INFINITY : az;
+                        cx = (cx != cx) ? INFINITY : cx; cy = (cy != cy) ? INFINITY : cy; cz = (cz != cz) ? INFINITY : cz;
+                        float lox = fminf(ax, cx), loy = fminf(ay, cy), loz = fminf(az, cz);
+                        float hix = fmaxf(ax, cx), hiy = fmaxf(ay, cy), hiz = fmaxf(az, cz);
+                        t1 = fmaxf(fmaxf(lox, 0.0f), fmaxf(loy, loz));
+                        t2 = fminf(fminf(hix, best_t), fminf(hiy, hiz));
+                    }
                     bool ok = (t1 <= t2) && (child != MP_LINK_NULL);  // Null links are skipped at pop in the reference (:49)
                     uint32_t m = static_cast<uint32_t>(__ballot(ok) >> (g * 8)) & 0xFFu;
                     if (ok) stack[sp + __popc(m & lanes_below)] = make_uint2(child, as_u(t1));  // ascending lane :161
@@ -258,6 +278,23 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
     wave_lds_sync();
 }
 
+// Exact conservative pre-test against the union of the root node's child boxes (DevScene::pre_min/pre_max): every
+// child box C lies inside that union U, and the slab interval of C is contained in the slab interval of U in
+// floating point too (IEEE subtraction and multiplication are monotone, and the NaN patches of aabb.rs:262-267 map
+// to the containing infinities), so a ray whose U interval is empty pushes no child of the root and is a miss.
+__device__ __forceinline__ bool may_hit_scene(const DevScene& sc, const Ray& r) {
+    if (!sc.has_pre) return true;
+    float ax = (sc.pre_min[0] - r.ox) * r.ix, ay = (sc.pre_min[1] - r.oy) * r.iy, az = (sc.pre_min[2] - r.oz) * r.iz;
+    float cx = (sc.pre_max[0] - r.ox) * r.ix, cy = (sc.pre_max[1] - r.oy) * r.iy, cz = (sc.pre_max[2] - r.oz) * r.iz;
+    ax = (ax != ax) ? -INFINITY : ax; ay = (ay != ay) ? -INFINITY : ay; az = (az != az) ? -INFINITY : az;
+    cx = (cx != cx) ? INFINITY : cx; cy = (cy != cy) ? INFINITY : cy; cz = (cz != cz) ? INFINITY : cz;
+    float lox = fminf(ax, cx), loy = fminf(ay, cy), loz = fminf(az, cz);
+    float hix = fmaxf(ax, cx), hiy = fmaxf(ay, cy), hiz = fmaxf(az, cz);
+    float t1 = fmaxf(fmaxf(lox, 0.0f), fmaxf(loy, loz));
+    float t2 = fminf(fminf(hix, FLT_MAX), fminf(hiy, hiz));
+    return t1 <= t2;
+}
+
 // Hit resolve + shade: tail of intersect (ray_bvh_intersection.rs:66-95) and render_sample (worker.rs:59-65).
 // Returns |dot(ray.direction, normal)|.
 __device__ __forceinline__ void resolve_normal(const DevScene& sc, uint32_t prim, float u, float v, float n[3]) {
@@ -291,6 +328,7 @@ struct RenderParams {
     uint32_t* counter;    // work-queue head
     float inv_spp;        // 1.0 / spp as f32 (worker.rs:44)
     uint32_t lds_per_wave;
+    uint32_t debug;       // timing-only ablations (MP_DEBUG env, never set in product use): 1 = skip traversal
 };
 
 // S = samples of one pixel in flight in a wavefront (64/S pixels x S consecutive samples per pass).
@@ -327,18 +365,19 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
             Ray r;
             r.dx = r.dy = r.dz = 0.0f;
             if (act) sample_ray(P.gen, px, py, s, r);
-            // compaction of the active lanes into the wave's ray queue
-            const uint64_t am = __ballot(act);
+            // compaction of the lanes whose ray can reach the scene into the wave's ray queue
+            const bool queued = act && may_hit_scene(P.scene, r);
+            const uint64_t am = __ballot(queued);
             const int n = __popcll(am), rank = __popcll(am & lanes_lt);
-            if (act) {
+            if (queued) {
                 q[0 * 64 + rank] = r.ox; q[1 * 64 + rank] = r.oy; q[2 * 64 + rank] = r.oz;
                 q[3 * 64 + rank] = r.dx; q[4 * 64 + rank] = r.dy; q[5 * 64 + rank] = r.dz;
                 q[6 * 64 + rank] = r.ix; q[7 * 64 + rank] = r.iy; q[8 * 64 + rank] = r.iz;
             }
             wave_lds_sync();
-            trace_wave(P.scene, q, stack, n);
+            if (!(P.debug & 1u)) trace_wave(P.scene, q, stack, n);
             float c = 0.0f, h = 0.0f;
-            if (act) {
+            if (queued && !(P.debug & 1u)) {
                 uint32_t prim = as_u(q[1 * 64 + rank]);
                 if (prim != kNoPrim) {
                     float nn[3];
@@ -364,6 +403,174 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
     }
 }
 
+
+// ---- ray-packet traversal (coherent rays) --------------------------------------------------------------------
+// One ray per lane, 64 rays share ONE traversal: the wavefront walks the BVH in the reference's canonical order
+// (children pushed in ascending index, popped in descending, ray_bvh_intersection.rs:52-54,161 -- the reference
+// never orders children by distance, so every ray's own visit sequence is a subsequence of this walk) and each lane
+// applies its own ray's tests: the pop-time cull `node_t1 > best.t` (:40), the slab test against its own best.t
+// (:149-162) and the triangle acceptance (:118-136).  A node / leaf is visited when at least one lane still needs
+// it; lanes that the reference would not take there are masked.  Node and triangle data are wave-uniform and come
+// through the scalar unit (s_load into SGPRs) from AoS copies of the scene; the per-lane entry distances of the
+// shared stack live in LDS.
+typedef const __attribute__((address_space(4))) float* kfp;      // constant address space => scalar loads
+typedef const __attribute__((address_space(4))) uint32_t* kup;
+
+constexpr float kTiny = 9.094947017729282e-13f;  // 2^-40
+constexpr float kHuge = 1099511627776.0f;        // 2^40
+
+// True when sign(num) != sign(det) and the quotient fl(fl(1/det) * num) is certainly a non-zero negative number
+// (|num| >= 2^-40 and |det| <= 2^40 keep |quotient| >= 2^-80(1-eps): no underflow to -0, which would pass `>= 0`).
+// det = +-0 or subnormal gives an infinite reciprocal whose sign still follows det.  NaN never rejects.
+__device__ __forceinline__ bool surely_negative(float num, float det) {
+    return (((as_u(num) ^ as_u(det)) >> 31) != 0u) && (fabsf(num) >= kTiny) && (fabsf(det) <= kHuge);
+}
+
+template <bool PATCH_NAN>
+__device__ __forceinline__ void slab(float bnx, float bny, float bnz, float bxx, float bxy, float bxz, const Ray& r,
+                                     float limit, float& t1, float& t2) {
+    // aabb.rs:254-284
+    float ax = (bnx - r.ox) * r.ix, ay = (bny - r.oy) * r.iy, az = (bnz - r.oz) * r.iz;
+    float cx = (bxx - r.ox) * r.ix, cy = (bxy - r.oy) * r.iy, cz = (bxz - r.oz) * r.iz;
+    if (PATCH_NAN) {  // only rays with an infinite inverse direction component can produce 0*inf (see trace_wave)
+        ax = (ax != ax) ? -INFINITY : ax; ay = (ay != ay) ? -INFINITY : ay; az = (az != az) ? -INFINITY : az;
+        cx = (cx != cx) ? INFINITY : cx; cy = (cy != cy) ? INFINITY : cy; cz = (cz != cz) ? INFINITY : cz;
+    }
+    float lox = fminf(ax, cx), loy = fminf(ay, cy), loz = fminf(az, cz);
+    float hix = fmaxf(ax, cx), hiy = fmaxf(ay, cy), hiz = fmaxf(az, cz);
+    t1 = fmaxf(fmaxf(lox, 0.0f), fmaxf(loy, loz));
+    t2 = fminf(fminf(hix, limit), fminf(hiy, hiz));
+}
+
+struct PacketHit {
+    float t, u, v;
+    uint32_t prim;
+};
+
+// `active` lanes carry a ray in r.  LDS per wave: float t1s[cap][64] then uint32 links[cap].
+template <bool PATCH_NAN>
+__device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, float* __restrict__ t1s,
+                                                  uint32_t* __restrict__ links, PacketHit& hit) {
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
+    kfp tris = (kfp)(uintptr_t)sc.tris_aos;
+    kup nvalid = (kup)(uintptr_t)sc.pkt_valid;
+    float best_t = FLT_MAX, bu = 0.0f, bv = 0.0f;  // best (:34-37)
+    uint32_t bprim = kNoPrim;
+    int sp = 1;
+    if (lane == 0) links[0] = sc.root;
+    t1s[lane] = active ? -INFINITY : INFINITY;  // :28-32 ; lanes without a ray never pass the cull test
+    wave_lds_sync();
+    while (sp > 0) {
+        sp--;
+        const uint32_t link = __builtin_amdgcn_readfirstlane(links[sp]);
+        const float node_t1 = t1s[sp * 64 + lane];
+        const bool on = !(node_t1 > best_t);  // :40-44, per ray
+        if (__ballot(on) == 0) continue;
+        if ((link & 7u) == 0u) {
+            // InnerNode::intersect :149-162, children ascending
+            kfp nd = nodes + static_cast<size_t>(link >> 3) * 64;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const uint32_t child = __builtin_amdgcn_readfirstlane(as_u(nd[c * 8 + 6]));
+                if (child == MP_LINK_NULL) continue;
+                float t1, t2;
+                slab<PATCH_NAN>(nd[c * 8 + 0], nd[c * 8 + 1], nd[c * 8 + 2], nd[c * 8 + 3], nd[c * 8 + 4], nd[c * 8 + 5], r,
+                                best_t, t1, t2);
+                const bool ok = on && (t1 <= t2);
+                if (__ballot(ok) != 0) {
+                    if (lane == 0) links[sp] = child;
+                    t1s[sp * 64 + lane] = ok ? t1 : INFINITY;
+                    sp++;
+                }
+            }
+            wave_lds_sync();
+        } else {
+            // intersect_triangles :104-140 ; every lane walks packets and triangles in ascending order, strict `<`
+            const uint32_t first = link >> 3, count = link & 7u;
+            for (uint32_t p = first; p < first + count; p++) {
+                const uint32_t nv = __builtin_amdgcn_readfirstlane(nvalid[p]);  // padding lanes can never be accepted
+                kfp tp = tris + static_cast<size_t>(p) * 96;
+                for (uint32_t i = 0; i < nv; i++, tp += 12) {
+                    const float v0x = tp[0], v0y = tp[1], v0z = tp[2];
+                    const float e1x = tp[3], e1y = tp[4], e1z = tp[5];
+                    const float e2x = tp[6], e2y = tp[7], e2z = tp[8];
+                    // triangle.rs:183-217
+                    float hx = fms(r.dy, e2z, r.dz * e2y), hy = fms(r.dz, e2x, r.dx * e2z), hz = fms(r.dx, e2y, r.dy * e2x);
+                    float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
+                    float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
+                    float un = fma_dot(sx, sy, sz, hx, hy, hz);
+                    bool possible = on && !surely_negative(un, det);  // u >= 0 cannot hold otherwise
+                    if (__ballot(possible) == 0) continue;
+                    float qx = fms(sy, e1z, sz * e1y), qy = fms(sz, e1x, sx * e1z), qz = fms(sx, e1y, sy * e1x);
+                    float vn = fma_dot(r.dx, r.dy, r.dz, qx, qy, qz);
+                    float tn = fma_dot(e2x, e2y, e2z, qx, qy, qz);
+                    possible = possible && !surely_negative(vn, det) && !surely_negative(tn, det);  // v >= 0, t >= 0
+                    if (__ballot(possible) == 0) continue;
+                    float inv_det = 1.0f / det;
+                    float u = inv_det * un, v = inv_det * vn, t = inv_det * tn;
+                    // mask & t>=0 & t<=max_t (:125) then strict `<` against the leaf best and the global best (:129,:59):
+                    // equivalent to a running strict `<` against best.t (best.t never exceeds max_t)
+                    bool acc = on && (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f) && (t < best_t);
+                    if (acc) { best_t = t; bu = u; bv = v; bprim = p * 8u + i; }
+                }
+            }
+        }
+    }
+    hit.t = best_t; hit.u = bu; hit.v = bv; hit.prim = bprim;
+}
+
+__device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, float* t1s, uint32_t* links,
+                                             PacketHit& hit) {
+    const bool slow = active && (fabsf(r.ix) == INFINITY || fabsf(r.iy) == INFINITY || fabsf(r.iz) == INFINITY);
+    if (__ballot(slow) == 0) trace_packet_impl<false>(sc, r, active, t1s, links, hit);
+    else trace_packet_impl<true>(sc, r, active, t1s, links, hit);
+}
+
+// Fused tile render on ray packets: each wave owns an 8x8 pixel block, all 64 lanes shoot sample s of their pixel.
+__global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
+    float* t1s = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P.lds_per_wave);
+    uint32_t* links = reinterpret_cast<uint32_t*>(t1s + static_cast<size_t>(P.scene.stack_cap) * 64);
+    const uint32_t ts = P.tile_size;
+    const uint32_t bx = (ts + 7) / 8, upt = bx * bx, total = P.n_tiles * upt;
+    const uint32_t spp = P.gen.spp;
+    for (;;) {
+        uint32_t unit = 0;
+        if (lane == 0) unit = atomicAdd(P.counter, 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        if (unit >= total) break;
+        const uint32_t tile_i = unit / upt, b = unit % upt;
+        const mp_block T = P.tiles[tile_i];
+        const uint32_t px = T.min_x + (b % bx) * 8 + static_cast<uint32_t>(lane & 7);
+        const uint32_t py = T.min_y + (b / bx) * 8 + static_cast<uint32_t>(lane >> 3);
+        const bool inpix = px < T.max_x && py < T.max_y;
+        if (__ballot(inpix) == 0) continue;
+        float acc = 0.0f, cnt = 0.0f;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
+        for (uint32_t s = 0; s < spp; s++) {
+            Ray r;
+            r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+            if (inpix) sample_ray(P.gen, px, py, s, r);
+            const bool go = inpix && may_hit_scene(P.scene, r);
+            PacketHit h;
+            h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
+            if (__ballot(go) != 0) trace_packet(P.scene, r, go, t1s, links, h);
+            if (h.prim != kNoPrim) {
+                float nn[3];
+                resolve_normal(P.scene, h.prim, h.u, h.v, nn);
+                acc += fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60, summed in sample order
+                cnt += 1.0f;
+            }
+        }
+        if (inpix) {
+            float m = acc * P.inv_spp;  // worker.rs:44
+            size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
+            *reinterpret_cast<float4*>(P.out + off) = make_float4(m, m, m, cnt * P.inv_spp);
+        }
+    }
+}
+
 // ---- batched Object::intersect over SoA ray streams (ray_bvh_intersection.rs:26-96) -------------------------
 struct TraceParams {
     DevScene scene;
@@ -383,21 +590,23 @@ __global__ __launch_bounds__(256) void trace_rays_kernel(TraceParams P) {
     for (uint64_t chunk = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave; chunk < chunks; chunk += stride) {
         const uint64_t i = chunk * 64 + lane;
         const bool act = i < P.n;
-        const int n = static_cast<int>(min(static_cast<uint64_t>(64), P.n - chunk * 64));
         Ray r;
-        r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = 0.0f;
-        if (act) {
-            ray_new(P.ox[i], P.oy[i], P.oz[i], P.dx[i], P.dy[i], P.dz[i], r);
-            q[0 * 64 + lane] = r.ox; q[1 * 64 + lane] = r.oy; q[2 * 64 + lane] = r.oz;
-            q[3 * 64 + lane] = r.dx; q[4 * 64 + lane] = r.dy; q[5 * 64 + lane] = r.dz;
-            q[6 * 64 + lane] = r.ix; q[7 * 64 + lane] = r.iy; q[8 * 64 + lane] = r.iz;
+        r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+        if (act) ray_new(P.ox[i], P.oy[i], P.oz[i], P.dx[i], P.dy[i], P.dz[i], r);
+        const bool queued = act && may_hit_scene(P.scene, r);
+        const uint64_t am = __ballot(queued);
+        const int n = __popcll(am), rank = __popcll(am & ((1ull << lane) - 1ull));
+        if (queued) {
+            q[0 * 64 + rank] = r.ox; q[1 * 64 + rank] = r.oy; q[2 * 64 + rank] = r.oz;
+            q[3 * 64 + rank] = r.dx; q[4 * 64 + rank] = r.dy; q[5 * 64 + rank] = r.dz;
+            q[6 * 64 + rank] = r.ix; q[7 * 64 + rank] = r.iy; q[8 * 64 + rank] = r.iz;
         }
         wave_lds_sync();
         trace_wave(P.scene, q, stack, n);
         if (act) {
-            float t = q[0 * 64 + lane];
-            uint32_t prim = as_u(q[1 * 64 + lane]);
-            float u = q[2 * 64 + lane], v = q[3 * 64 + lane];
+            float t = queued ? q[0 * 64 + rank] : FLT_MAX;
+            uint32_t prim = queued ? as_u(q[1 * 64 + rank]) : kNoPrim;
+            float u = queued ? q[2 * 64 + rank] : 0.0f, v = queued ? q[3 * 64 + rank] : 0.0f;
             if (P.hits.d_t) P.hits.d_t[i] = t;
             if (P.hits.d_prim) P.hits.d_prim[i] = prim;
             if (P.hits.d_u) P.hits.d_u[i] = u;
@@ -510,15 +719,25 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     P.counter = L.d_counter;
     P.inv_spp = 1.0f / static_cast<float>(L.spp);
     P.lds_per_wave = lds_bytes_per_wave(L.scene.stack_cap);
+    P.debug = getenv("MP_DEBUG") ? static_cast<uint32_t>(atoi(getenv("MP_DEBUG"))) : 0u;
     const uint32_t lds = P.lds_per_wave * 4;
     if (lds > 160 * 1024) { err = "scene too deep for the LDS traversal stacks"; return MP_ERR_UNSUPPORTED; }
     int rc = check(hipMemsetAsync(L.d_counter, 0, sizeof(uint32_t), st), "hipMemsetAsync(counter)", err);
     if (rc) return rc;
     const uint64_t units = static_cast<uint64_t>(L.n_tiles) * ((L.tile_size + 7) / 8) * ((L.tile_size + 7) / 8);
     const uint64_t want = (units + 3) / 4;
-    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * 8));
-    hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);
-    return check(hipGetLastError(), "render_tiles_kernel launch", err);
+    if (L.traversal == 1) {
+        const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * 8));
+        hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);
+        return check(hipGetLastError(), "render_tiles_kernel launch", err);
+    }
+    P.lds_per_wave = L.scene.stack_cap * 65u * 4u;
+    const uint32_t plds = P.lds_per_wave * 4;
+    if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
+    const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds));
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * per_cu));
+    hipLaunchKernelGGL(render_tiles_packet_kernel, dim3(grid), dim3(256), plds, st, P);
+    return check(hipGetLastError(), "render_tiles_packet_kernel launch", err);
 }
 
 int launch_trace_rays(const DevScene& sc, const float* ox, const float* oy, const float* oz, const float* dx,

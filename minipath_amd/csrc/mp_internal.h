@@ -65,12 +65,21 @@ struct DevScene {
     const float* nodes = nullptr;
     const float* tris = nullptr;
     const float* shade = nullptr;
+    // AoS copies of the same values for wave-uniform (scalar-unit) fetch by the ray-packet traversal:
+    // nodes_aos: inner x 8 children x 8 dwords {minx,miny,minz,maxx,maxy,maxz,link,0} ; tris_aos: packets x 8 x 12
+    // dwords {v0.xyz,e1.xyz,e2.xyz,0,0,0} ; pkt_valid: real (unpadded) triangles of each packet
+    const float* nodes_aos = nullptr;
+    const float* tris_aos = nullptr;
+    const uint32_t* pkt_valid = nullptr;
     const uint32_t* vidx = nullptr;  // packets*8*3
     const float* vtex = nullptr;     // nv*3
     uint32_t root = MP_LINK_NULL;
     uint32_t inner_count = 0;
     uint32_t packet_count = 0;
     uint32_t stack_cap = 1;          // 7*depth+1
+    // union of the root inner node's (non-null) decompressed child boxes: exact conservative ray pre-test
+    uint32_t has_pre = 0;
+    float pre_min[3] = {0, 0, 0}, pre_max[3] = {0, 0, 0};
 };
 
 constexpr int kNodeDwords = 56;
@@ -87,6 +96,7 @@ struct RenderLaunch {
     float* d_out;              // tile-major f32 RGBA
     uint32_t* d_counter;       // work-queue head, zeroed by the launcher
     int cu_count;
+    int traversal;             // 0 = ray packets (coherent camera rays), 1 = 8-lane groups
 };
 
 int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err);

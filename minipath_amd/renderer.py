@@ -23,13 +23,19 @@ class RenderSettings:
     resolution: tuple
     seed: int = 0x5EED
     shuffle_tiles: bool = False
+    traversal: str = "packets"  # "packets": 64 camera rays per wave share one BVH walk; "groups": 8 lanes per ray
 
     def as_struct(self) -> _lib.SettingsStruct:
         if self.tile_size <= 0 or self.sample_count <= 0:
             raise ValueError("tile_size and sample_count are NonZeroU32")
+        if self.traversal not in ("packets", "groups"):
+            raise ValueError("traversal is 'packets' or 'groups'")
         return _lib.SettingsStruct(
             int(self.tile_size), int(self.sample_count), int(self.resolution[0]), int(self.resolution[1]),
-            int(self.seed) & 0xFFFFFFFFFFFFFFFF, _lib.MP_FLAG_SHUFFLE_TILES if self.shuffle_tiles else 0, 0,
+            int(self.seed) & 0xFFFFFFFFFFFFFFFF,
+            (_lib.MP_FLAG_SHUFFLE_TILES if self.shuffle_tiles else 0)
+            | (_lib.MP_FLAG_TRAVERSAL_GROUPS if self.traversal == "groups" else 0),
+            0,
         )
 
 

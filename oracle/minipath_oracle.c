@@ -990,6 +990,16 @@ static inline void stack_push(stack_cache *s, const stack_entry *x) {
 
 typedef struct { float t, u, v; float gn[3]; uint64_t prim; } leaf_hit; /* :165-171 */
 
+/* optional per-ray operation trace for scheduling studies (tools/sim_sched.py): one byte per stack pop:
+ * 0 = culled/null, 1 = inner node tested, 8+k = leaf with k packets tested.  Not part of the restatement. */
+static _Thread_local uint8_t *g_ops = NULL;
+static _Thread_local uint32_t *g_links = NULL;
+static _Thread_local size_t g_ops_cap = 0, g_ops_n = 0;
+static _Thread_local uint32_t g_cur_link = 0;
+static inline void op_rec(uint8_t v) {
+    if (g_ops && g_ops_n < g_ops_cap) { if (g_links) g_links[g_ops_n] = g_cur_link; g_ops[g_ops_n++] = v; }
+}
+
 static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache *st, mpo_hit *out, mpo_counters *cnt) {
     st->n = 0;
     stack_entry root;
@@ -1005,10 +1015,12 @@ static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache
         if (cnt && st->n > cnt->max_stack) cnt->max_stack = st->n;
         stack_entry e = st->e[--st->n];
         if (cnt) cnt->stack_pops++;
-        if (e.t1 > best.t) continue; /* :40-44 */
+        g_cur_link = e.link;
+        if (e.t1 > best.t) { op_rec(0); continue; } /* :40-44 */
         uint32_t index, count;
         int kind = mpo_link_decode(e.link, &index, &count);
-        if (kind == 0) continue; /* Null :49 */
+        if (kind == 0) { op_rec(0); continue; } /* Null :49 */
+        op_rec(kind == 1 ? 1 : (uint8_t)(8 + count));
         if (kind == 1) {
             /* InnerNode::intersect :149-162 */
             const mpo_inner_node *node = &b->inner[index];
@@ -1081,6 +1093,17 @@ static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache
     normalize3(n, out->normal);
     mpo_ray_point_at(ray, best.t, out->point);
     out->material = 0;
+}
+
+size_t mpo_bvh_intersect_ops(const mpo_bvh *b, const mpo_ray *ray, uint8_t *ops, uint32_t *links, size_t cap) {
+    stack_cache st = {0};
+    mpo_hit h;
+    g_ops = ops; g_links = links; g_ops_cap = cap; g_ops_n = 0;
+    bvh_intersect_impl(b, ray, &st, &h, NULL);
+    size_t n = g_ops_n;
+    g_ops = NULL; g_links = NULL; g_ops_cap = 0; g_ops_n = 0;
+    free(st.e);
+    return n;
 }
 
 void mpo_bvh_intersect(const mpo_bvh *b, const mpo_ray *ray, mpo_hit *out, mpo_counters *cnt) {

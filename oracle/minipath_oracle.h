@@ -170,6 +170,8 @@ const float *mpo_bvh_vertex_tex(const mpo_bvh *b);            /* nv*3 */
 
 /* ---- ray_bvh_intersection.rs ---------------------------------------------------------------------- */
 void mpo_bvh_intersect(const mpo_bvh *b, const mpo_ray *ray, mpo_hit *out, mpo_counters *cnt);  /* :26-96 */
+/* diagnostics only: per-pop operation trace of one ray (0 culled, 1 inner, 8+k leaf of k packets) */
+size_t mpo_bvh_intersect_ops(const mpo_bvh *b, const mpo_ray *ray, uint8_t *ops, uint32_t *links, size_t cap);
 /* batched: rays as SoA ox,oy,oz,dx,dy,dz (directions need not be normalised: Ray::new is applied) */
 void mpo_trace_rays(const mpo_bvh *b, const float *ox, const float *oy, const float *oz, const float *dx,
                     const float *dy, const float *dz, uint64_t n, float *t, uint32_t *prim, float *u, float *v,

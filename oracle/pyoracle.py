@@ -155,6 +155,8 @@ def lib() -> C.CDLL:
         fn.argtypes = [C.c_void_p]
         fn.restype = C.c_void_p
     L.mpo_bvh_intersect.argtypes = [C.c_void_p, C.POINTER(Ray), C.POINTER(Hit), C.POINTER(Counters)]
+    L.mpo_bvh_intersect_ops.argtypes = [C.c_void_p, C.POINTER(Ray), C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.c_size_t]
+    L.mpo_bvh_intersect_ops.restype = C.c_size_t
     L.mpo_trace_rays.argtypes = [C.c_void_p] + [f32p] * 6 + [C.c_uint64, f32p, u32p, f32p, f32p, C.POINTER(Counters)]
     L.mpo_render_sample.argtypes = [
         C.c_void_p, C.POINTER(Sampler), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,

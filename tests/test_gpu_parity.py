@@ -152,6 +152,7 @@ def test_generate_rays_matches_sample_ray(ctx, oracle):
             assert np.array_equal(bits(np.array([g[k][i] for k in range(6)], np.float32)), bits(exp)), (x, y, sample)
 
 
+@pytest.mark.parametrize("traversal", ["packets", "groups"])
 @pytest.mark.parametrize(
     "res,tile_size,spp,tile",
     [
@@ -162,10 +163,11 @@ def test_generate_rays_matches_sample_ray(ctx, oracle):
         ((256, 256), 64, 3, (0, 0, 64, 64)),          # background-only tile
     ],
 )
-def test_render_tile_bit_exact(teapot, oracle, teapot_oracle_bvh, res, tile_size, spp, tile):
-    """Worker::render_tile (worker.rs:32-49): f32 means bit-exact (<= 1e-5 rel required), u8 exact."""
+def test_render_tile_bit_exact(teapot, oracle, teapot_oracle_bvh, res, tile_size, spp, tile, traversal):
+    """Worker::render_tile (worker.rs:32-49): f32 means bit-exact (<= 1e-5 rel required), u8 exact; both the
+    ray-packet and the 8-lane-group traversal."""
     cam = mp.Camera.teapot_view()
-    st = mp.RenderSettings(tile_size, spp, res, seed=SEED)
+    st = mp.RenderSettings(tile_size, spp, res, seed=SEED, traversal=traversal)
     f, u8 = mp.render_tile(teapot, cam.build_sampler(res), st, mp.ScreenBlock(*tile))
     of, ou8 = teapot_oracle_bvh.render_tile(oracle.build_sampler(oracle.teapot_camera(), *res), res[0], res[1], spp, SEED, *tile)
     rel = np.abs(f - of) / np.maximum(np.abs(of), 1e-30)
@@ -185,13 +187,14 @@ def test_render_tile_empty_and_invalid(teapot):
         mp.render_tile(teapot, cam.build_sampler((256, 256)), st, mp.ScreenBlock(224, 224, 288, 288))
 
 
-def test_c1_frame_matches_oracle(teapot, oracle, teapot_oracle_bvh):
+@pytest.mark.parametrize("traversal", ["packets", "groups"])
+def test_c1_frame_matches_oracle(teapot, oracle, teapot_oracle_bvh, traversal):
     """BASELINE config C1 (teapot 256x256, 16 spp): the whole frame through the one-launch device path + untile,
     against the oracle's threaded render (machinery.rs semantics): f32 bit-exact, u8 exact."""
     import torch
 
     cam = mp.Camera.teapot_view()
-    st = mp.RenderSettings(64, 16, (256, 256), seed=SEED)
+    st = mp.RenderSettings(64, 16, (256, 256), seed=SEED, traversal=traversal)
     fr = mp.FrameRenderer(teapot, cam, st)
     fr.render()
     img, img8 = fr.untile()
@@ -335,3 +338,34 @@ def test_golden_fixtures(teapot, ctx):
     f, u8 = mp.render_tile(teapot, mp.Camera.teapot_view().build_sampler((256, 256)), st, mp.ScreenBlock(*[int(v) for v in g["tile"]]))
     assert np.array_equal(bits(f), g["tile_f32_bits"])
     assert np.array_equal(u8, g["tile_u8"])
+
+
+@pytest.mark.parametrize("traversal", ["packets", "groups"])
+@pytest.mark.parametrize("name", ["soup_5000", "grid_40", "sphere_24", "sliver_fan", "soup_300"])
+def test_render_synthetic_scenes(ctx, oracle, name, traversal):
+    """Whole small frames of synthetic scenes (flat shading, deep trees, shared-edge ties) against the oracle,
+    with a camera looking at the scene: exercises the packet walk with partially culled lanes."""
+    import ctypes as C
+
+    pos, nrm, tex, tri = meshes.make(name)
+    scene = mp.Scene(mp.TriangleBvh.build(pos, nrm, tex, tri, ctx))
+    orc = oracle.Bvh.build(pos, nrm, tex, tri)
+    bmin, bmax = orc.bbox()
+    ctr = (bmin + bmax) / 2
+    ext = float(np.max(bmax - bmin))
+    eye = ctr + np.array([0.9, 0.7, 1.6], np.float32) * ext
+    cam = mp.Camera.default().look_at(tuple(eye), tuple(ctr), (0, 1, 0)).f_number(2.0).sensor_height(36e-3)
+    oc = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(oc))
+    oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(*eye), oracle.vec3(*ctr), oracle.vec3(0, 1, 0))
+    oc.f_number = 2.0
+    oc.sensor_size = 36e-3
+    res = (96, 72)
+    st = mp.RenderSettings(32, 3, res, seed=11, traversal=traversal)
+    fr = mp.FrameRenderer(scene, cam, st)
+    fr.render()
+    img, img8 = fr.untile()
+    of, ou8, *_ = orc.render_image_mt(oracle.build_sampler(oc, *res), res[0], res[1], 3, 11, 32, 4)
+    assert np.array_equal(bits(img.cpu().numpy()), bits(of))
+    assert np.array_equal(img8.cpu().numpy(), ou8)
+    assert (of[..., 3] > 0).mean() > 0.05
