@@ -447,29 +447,53 @@ struct PacketHit {
     uint32_t prim;
 };
 
-// `active` lanes carry a ray in r.  LDS per wave: float t1s[cap][64] then uint32 links[cap].
+// The shared traversal stack is wave-uniform and lives in four VGPRs used as 64-entry arrays (entry k = lane k,
+// written with a lane-select, read with v_readlane and a scalar index): link, source slot (node*8+child, to re-derive
+// the entry distance) and the 64-bit mask of lanes that passed the slab test when the entry was pushed.
+// The pop-time cull `node_t1 > best.t` (:40) needs the ray's own entry distance t1: it can only fire for a lane
+// whose best.t shrank after the push, so while no lane accepted a hit since then (entry not "stale") the pushed
+// mask is the answer; otherwise t1 is recomputed from the child's box (same operations, same bits as at push time).
+constexpr uint32_t kSrcRoot = 0xFFFFFFFFu;
+constexpr int kPacketStackMax = 64;
+
 template <bool PATCH_NAN>
-__device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, float* __restrict__ t1s,
-                                                  uint32_t* __restrict__ links, PacketHit& hit) {
+__device__ __forceinline__ float slab_entry(float bnx, float bny, float bnz, float bxx, float bxy, float bxz, const Ray& r) {
+    float t1, t2;
+    slab<PATCH_NAN>(bnx, bny, bnz, bxx, bxy, bxz, r, FLT_MAX, t1, t2);
+    return t1;
+}
+
+template <bool PATCH_NAN>
+__device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, PacketHit& hit) {
     const int lane = static_cast<int>(threadIdx.x) & 63;
     kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
     kfp tris = (kfp)(uintptr_t)sc.tris_aos;
     kup nvalid = (kup)(uintptr_t)sc.pkt_valid;
     float best_t = FLT_MAX, bu = 0.0f, bv = 0.0f;  // best (:34-37)
     uint32_t bprim = kNoPrim;
+    // the stack (see above); entry 0 = root (:28-32), t1 = -inf: never culled
+    const uint64_t m0 = __ballot(active);
+    int st_link = static_cast<int>(sc.root), st_src = static_cast<int>(kSrcRoot);
+    int st_mlo = static_cast<int>(static_cast<uint32_t>(m0)), st_mhi = static_cast<int>(static_cast<uint32_t>(m0 >> 32));
+    uint64_t stale = 0;  // bit k: some lane's best.t changed after entry k was pushed
     int sp = 1;
-    if (lane == 0) links[0] = sc.root;
-    t1s[lane] = active ? -INFINITY : INFINITY;  // :28-32 ; lanes without a ray never pass the cull test
-    wave_lds_sync();
     while (sp > 0) {
         sp--;
-        const uint32_t link = __builtin_amdgcn_readfirstlane(links[sp]);
-        const float node_t1 = t1s[sp * 64 + lane];
-        const bool on = !(node_t1 > best_t);  // :40-44, per ray
+        const uint32_t link = static_cast<uint32_t>(__builtin_amdgcn_readlane(st_link, sp));
+        const uint32_t src = static_cast<uint32_t>(__builtin_amdgcn_readlane(st_src, sp));
+        const uint64_t pm = static_cast<uint32_t>(__builtin_amdgcn_readlane(st_mlo, sp)) |
+                            (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(st_mhi, sp))) << 32);
+        bool on = ((pm >> lane) & 1ull) != 0ull;
+        if (((stale >> sp) & 1ull) != 0ull && src != kSrcRoot) {  // :40-44, per ray
+            kfp bx = nodes + static_cast<size_t>(src) * 8;
+            const float node_t1 = slab_entry<PATCH_NAN>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], r);
+            on = on && !(node_t1 > best_t);
+        }
         if (__ballot(on) == 0) continue;
         if ((link & 7u) == 0u) {
             // InnerNode::intersect :149-162, children ascending
-            kfp nd = nodes + static_cast<size_t>(link >> 3) * 64;
+            const uint32_t node = link >> 3;
+            kfp nd = nodes + static_cast<size_t>(node) * 64;
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const uint32_t child = __builtin_amdgcn_readfirstlane(as_u(nd[c * 8 + 6]));
@@ -477,62 +501,66 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 float t1, t2;
                 slab<PATCH_NAN>(nd[c * 8 + 0], nd[c * 8 + 1], nd[c * 8 + 2], nd[c * 8 + 3], nd[c * 8 + 4], nd[c * 8 + 5], r,
                                 best_t, t1, t2);
-                const bool ok = on && (t1 <= t2);
-                if (__ballot(ok) != 0) {
-                    if (lane == 0) links[sp] = child;
-                    t1s[sp * 64 + lane] = ok ? t1 : INFINITY;
+                const uint64_t okm = __ballot(on && (t1 <= t2));
+                if (okm != 0) {
+                    const bool slot = lane == sp;
+                    st_link = slot ? static_cast<int>(child) : st_link;
+                    st_src = slot ? static_cast<int>(node * 8u + c) : st_src;
+                    st_mlo = slot ? static_cast<int>(static_cast<uint32_t>(okm)) : st_mlo;
+                    st_mhi = slot ? static_cast<int>(static_cast<uint32_t>(okm >> 32)) : st_mhi;
+                    stale &= ~(1ull << sp);
                     sp++;
                 }
             }
-            wave_lds_sync();
         } else {
-            // intersect_triangles :104-140 ; every lane walks packets and triangles in ascending order, strict `<`
+            // intersect_triangles :104-140 ; every lane walks the leaf's triangles in (packet, lane) order with a
+            // strict `<`.  Padding (only at the tail of the last packet) can never be accepted and is not visited.
             const uint32_t first = link >> 3, count = link & 7u;
-            for (uint32_t p = first; p < first + count; p++) {
-                const uint32_t nv = __builtin_amdgcn_readfirstlane(nvalid[p]);  // padding lanes can never be accepted
-                kfp tp = tris + static_cast<size_t>(p) * 96;
-                for (uint32_t i = 0; i < nv; i++, tp += 12) {
-                    const float v0x = tp[0], v0y = tp[1], v0z = tp[2];
-                    const float e1x = tp[3], e1y = tp[4], e1z = tp[5];
-                    const float e2x = tp[6], e2y = tp[7], e2z = tp[8];
-                    // triangle.rs:183-217
-                    float hx = fms(r.dy, e2z, r.dz * e2y), hy = fms(r.dz, e2x, r.dx * e2z), hz = fms(r.dx, e2y, r.dy * e2x);
-                    float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
-                    float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
-                    float un = fma_dot(sx, sy, sz, hx, hy, hz);
-                    bool possible = on && !surely_negative(un, det);  // u >= 0 cannot hold otherwise
-                    if (__ballot(possible) == 0) continue;
+            const uint32_t n_real = (count - 1u) * 8u + __builtin_amdgcn_readfirstlane(nvalid[first + count - 1u]);
+            kfp tp = tris + static_cast<size_t>(first) * 96;
+            bool changed = false;
+            float v0x = tp[0], v0y = tp[1], v0z = tp[2], e1x = tp[3], e1y = tp[4], e1z = tp[5], e2x = tp[6], e2y = tp[7], e2z = tp[8];
+            for (uint32_t i = 0; i < n_real; i++) {
+                tp += 12;  // prefetch of the next triangle (the array has one triangle of tail padding)
+                const float n0 = tp[0], n1 = tp[1], n2 = tp[2], n3 = tp[3], n4 = tp[4], n5 = tp[5], n6 = tp[6], n7 = tp[7], n8 = tp[8];
+                // triangle.rs:183-217
+                float hx = fms(r.dy, e2z, r.dz * e2y), hy = fms(r.dz, e2x, r.dx * e2z), hz = fms(r.dx, e2y, r.dy * e2x);
+                float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
+                float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
+                float un = fma_dot(sx, sy, sz, hx, hy, hz);
+                bool possible = on && !surely_negative(un, det);  // u >= 0 cannot hold otherwise
+                if (__ballot(possible) != 0) {
                     float qx = fms(sy, e1z, sz * e1y), qy = fms(sz, e1x, sx * e1z), qz = fms(sx, e1y, sy * e1x);
                     float vn = fma_dot(r.dx, r.dy, r.dz, qx, qy, qz);
                     float tn = fma_dot(e2x, e2y, e2z, qx, qy, qz);
                     possible = possible && !surely_negative(vn, det) && !surely_negative(tn, det);  // v >= 0, t >= 0
-                    if (__ballot(possible) == 0) continue;
-                    float inv_det = 1.0f / det;
-                    float u = inv_det * un, v = inv_det * vn, t = inv_det * tn;
-                    // mask & t>=0 & t<=max_t (:125) then strict `<` against the leaf best and the global best (:129,:59):
-                    // equivalent to a running strict `<` against best.t (best.t never exceeds max_t)
-                    bool acc = on && (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f) && (t < best_t);
-                    if (acc) { best_t = t; bu = u; bv = v; bprim = p * 8u + i; }
+                    if (__ballot(possible) != 0) {
+                        float inv_det = 1.0f / det;
+                        float u = inv_det * un, v = inv_det * vn, t = inv_det * tn;
+                        // mask & t>=0 & t<=max_t (:125), strict `<` vs the leaf best, then vs the global best (:129,:59):
+                        // equivalent to a running strict `<` against best.t (best.t never exceeds max_t)
+                        bool acc = on && (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f) && (t < best_t);
+                        if (acc) { best_t = t; bu = u; bv = v; bprim = first * 8u + i; }
+                        changed = changed || acc;
+                    }
                 }
+                v0x = n0; v0y = n1; v0z = n2; e1x = n3; e1y = n4; e1z = n5; e2x = n6; e2y = n7; e2z = n8;
             }
+            if (__ballot(changed) != 0) stale = ~0ull;  // every entry still on the stack predates this change
         }
     }
     hit.t = best_t; hit.u = bu; hit.v = bv; hit.prim = bprim;
 }
 
-__device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, float* t1s, uint32_t* links,
-                                             PacketHit& hit) {
+__device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, PacketHit& hit) {
     const bool slow = active && (fabsf(r.ix) == INFINITY || fabsf(r.iy) == INFINITY || fabsf(r.iz) == INFINITY);
-    if (__ballot(slow) == 0) trace_packet_impl<false>(sc, r, active, t1s, links, hit);
-    else trace_packet_impl<true>(sc, r, active, t1s, links, hit);
+    if (__ballot(slow) == 0) trace_packet_impl<false>(sc, r, active, hit);
+    else trace_packet_impl<true>(sc, r, active, hit);
 }
 
 // Fused tile render on ray packets: each wave owns an 8x8 pixel block, all 64 lanes shoot sample s of their pixel.
 __global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
-    float* t1s = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P.lds_per_wave);
-    uint32_t* links = reinterpret_cast<uint32_t*>(t1s + static_cast<size_t>(P.scene.stack_cap) * 64);
+    const int lane = static_cast<int>(threadIdx.x) & 63;
     const uint32_t ts = P.tile_size;
     const uint32_t bx = (ts + 7) / 8, upt = bx * bx, total = P.n_tiles * upt;
     const uint32_t spp = P.gen.spp;
@@ -555,7 +583,7 @@ __global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P
             const bool go = inpix && may_hit_scene(P.scene, r);
             PacketHit h;
             h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
-            if (__ballot(go) != 0) trace_packet(P.scene, r, go, t1s, links, h);
+            if (__ballot(go) != 0 && !(P.debug & 1u)) trace_packet(P.scene, r, go, h);
             if (h.prim != kNoPrim) {
                 float nn[3];
                 resolve_normal(P.scene, h.prim, h.u, h.v, nn);
@@ -731,12 +759,13 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);
         return check(hipGetLastError(), "render_tiles_kernel launch", err);
     }
-    P.lds_per_wave = L.scene.stack_cap * 65u * 4u;
-    const uint32_t plds = P.lds_per_wave * 4;
-    if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
-    const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds));
-    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * per_cu));
-    hipLaunchKernelGGL(render_tiles_packet_kernel, dim3(grid), dim3(256), plds, st, P);
+    if (L.scene.stack_cap > static_cast<uint32_t>(kPacketStackMax)) {  // deeper than 9 levels: use the group traversal
+        const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * 8));
+        hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);
+        return check(hipGetLastError(), "render_tiles_kernel launch", err);
+    }
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * 8));
+    hipLaunchKernelGGL(render_tiles_packet_kernel, dim3(grid), dim3(256), 0, st, P);
     return check(hipGetLastError(), "render_tiles_packet_kernel launch", err);
 }
 
