@@ -558,11 +558,19 @@ __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, b
     else trace_packet_impl<true>(sc, r, active, hit);
 }
 
-// Fused tile render on ray packets: each wave owns an 8x8 pixel block, all 64 lanes shoot sample s of their pixel.
+// Fused tile render on ray packets.  A wave owns a block of 64/S pixels and shoots S consecutive samples of each
+// pixel per pass (lane = pixel*S + sub-sample): all 64 rays of a pass are neighbours on the film, so the packet stays
+// coherent, while the work unit (block x all samples) shrinks with S, which evens out the load.  pixel_sum is
+// accumulated strictly in sample order (worker.rs:41-43) by the lane with sub-sample 0.
+template <int S>
 __global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P) {
+    constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : (S <= 32) ? 2 : 1;  // pixel block = BW x BH, BW*BH*S == 64
+    constexpr int BH = 64 / S / BW;
     const int lane = static_cast<int>(threadIdx.x) & 63;
+    const int pix = lane / S, sub = lane % S;
+    const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1));
     const uint32_t ts = P.tile_size;
-    const uint32_t bx = (ts + 7) / 8, upt = bx * bx, total = P.n_tiles * upt;
+    const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
     const uint32_t spp = P.gen.spp;
     for (;;) {
         uint32_t unit = 0;
@@ -571,27 +579,38 @@ __global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P
         if (unit >= total) break;
         const uint32_t tile_i = unit / upt, b = unit % upt;
         const mp_block T = P.tiles[tile_i];
-        const uint32_t px = T.min_x + (b % bx) * 8 + static_cast<uint32_t>(lane & 7);
-        const uint32_t py = T.min_y + (b / bx) * 8 + static_cast<uint32_t>(lane >> 3);
+        const uint32_t px = T.min_x + (b % bx) * BW + static_cast<uint32_t>(pix % BW);
+        const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
         const bool inpix = px < T.max_x && py < T.max_y;
         if (__ballot(inpix) == 0) continue;
         float acc = 0.0f, cnt = 0.0f;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
-        for (uint32_t s = 0; s < spp; s++) {
+        for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+            const uint32_t s = s0 + static_cast<uint32_t>(sub);
+            const bool act = inpix && s < spp;
             Ray r;
             r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
-            if (inpix) sample_ray(P.gen, px, py, s, r);
-            const bool go = inpix && may_hit_scene(P.scene, r);
+            if (act) sample_ray(P.gen, px, py, s, r);
+            const bool go = act && may_hit_scene(P.scene, r);
             PacketHit h;
             h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
-            if (__ballot(go) != 0 && !(P.debug & 1u)) trace_packet(P.scene, r, go, h);
-            if (h.prim != kNoPrim) {
+            if (__ballot(go) != 0) trace_packet(P.scene, r, go, h);
+            float c = 0.0f;
+            const bool hit = h.prim != kNoPrim;
+            if (hit) {
                 float nn[3];
                 resolve_normal(P.scene, h.prim, h.u, h.v, nn);
-                acc += fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60, summed in sample order
-                cnt += 1.0f;
+                c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60
+            }
+            // alpha sums 1.0 per hit: an exact integer in f32, so the order is irrelevant
+            cnt += static_cast<float>(__popcll(__ballot(hit) & pixel_lanes));
+            if (S == 1) {
+                acc += c;
+            } else {
+#pragma unroll
+                for (int j = 0; j < S; j++) acc += __shfl(c, (lane & ~(S - 1)) + j);  // misses add +0.0 (exact)
             }
         }
-        if (inpix) {
+        if (inpix && sub == 0) {
             float m = acc * P.inv_spp;  // worker.rs:44
             size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
             *reinterpret_cast<float4*>(P.out + off) = make_float4(m, m, m, cnt * P.inv_spp);
@@ -764,8 +783,18 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);
         return check(hipGetLastError(), "render_tiles_kernel launch", err);
     }
-    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * 8));
-    hipLaunchKernelGGL(render_tiles_packet_kernel, dim3(grid), dim3(256), 0, st, P);
+    // samples of one pixel in flight per pass: 8 keeps the 64 rays of a pass within a 4x2 pixel footprint and makes
+    // the work units 8x smaller than a whole 8x8 block (measured best on MI355X: profiles/r01_notes.md)
+    int S = L.spp >= 8 ? 8 : L.spp >= 4 ? 4 : L.spp >= 2 ? 2 : 1;
+    if (getenv("MP_S")) S = atoi(getenv("MP_S"));  // experiments only
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want * S, static_cast<uint64_t>(L.cu_count) * 8));
+    if (S == 2) hipLaunchKernelGGL(render_tiles_packet_kernel<2>, dim3(grid), dim3(256), 0, st, P);
+    else if (S == 4) hipLaunchKernelGGL(render_tiles_packet_kernel<4>, dim3(grid), dim3(256), 0, st, P);
+    else if (S == 8) hipLaunchKernelGGL(render_tiles_packet_kernel<8>, dim3(grid), dim3(256), 0, st, P);
+    else if (S == 16) hipLaunchKernelGGL(render_tiles_packet_kernel<16>, dim3(grid), dim3(256), 0, st, P);
+    else if (S == 32) hipLaunchKernelGGL(render_tiles_packet_kernel<32>, dim3(grid), dim3(256), 0, st, P);
+    else if (S == 64) hipLaunchKernelGGL(render_tiles_packet_kernel<64>, dim3(grid), dim3(256), 0, st, P);
+    else hipLaunchKernelGGL(render_tiles_packet_kernel<1>, dim3(grid), dim3(256), 0, st, P);
     return check(hipGetLastError(), "render_tiles_packet_kernel launch", err);
 }
 
