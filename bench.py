@@ -40,8 +40,9 @@ def parse():
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "teapot.obj"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-tile-stride", type=int, default=16, help="cpu_baseline renders every k-th tile")
+    ap.add_argument("--cpu-tile-stride", type=int, default=11, help="cpu_baseline renders every k-th tile")
     ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on cpu_baseline worker threads")
+    ap.add_argument("--traversal", default="packets", choices=["packets", "groups"])
     ap.add_argument("--check", action="store_true", help="compare a few tiles of the GPU frame with the oracle")
     return ap.parse_args()
 
@@ -94,50 +95,24 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    from minipath_amd.distributed import DistributedFrame
+
     ctx = mp.Context(local_rank)
     scene = mp.Scene(mp.TriangleBvh.with_obj(args.scene, ctx))
     cam = mp.Camera.teapot_view()
-    st = mp.RenderSettings(args.tile, args.spp, (args.width, args.height), seed=args.seed)
-    all_tiles = mp.tile_ordering(mp.ScreenBlock(0, 0, args.width, args.height), args.tile)
-    my_tiles = all_tiles[rank::world]
-    fr = mp.FrameRenderer(scene, cam, st, tiles=my_tiles)
-    per_rank = (len(all_tiles) + world - 1) // world
-    ts = args.tile
-    # equal-size shards for the gather; rank-major tile list for the un-tile on rank 0
-    shard = torch.zeros((per_rank, ts, ts, 4), dtype=torch.float32, device=dev)
-    gathered = [torch.zeros_like(shard) for _ in range(world)] if (world > 1 and rank == 0) else None
-    gather_tiles = []
-    for r in range(world):
-        tl = all_tiles[r::world]
-        gather_tiles += tl + [mp.ScreenBlock(0, 0, 0, 0)] * (per_rank - len(tl))
-    full_fr = mp.FrameRenderer(scene, cam, st, tiles=all_tiles[:1]) if rank == 0 else None  # untile helper only
+    st = mp.RenderSettings(args.tile, args.spp, (args.width, args.height), seed=args.seed, traversal=args.traversal)
+    frame = DistributedFrame(scene, cam, st, rank, world)
+    all_tiles = frame.all_tiles
     total_rays = args.width * args.height * args.spp
     events = []
 
     def step(timed):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        buf = fr.render()
-        ev1.record()
-        img = None
-        if world > 1:
-            shard[: len(my_tiles)].copy_(buf[: len(my_tiles)])
-            dist.gather(shard, gathered, dst=0)
-            if rank == 0:
-                img, _ = untile_gathered()
-        else:
-            img, _ = fr.untile(want_u8=True)
+        """Render my shard (one launch), gather to rank 0 over RCCL, un-tile there."""
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        img, _ = frame.step(want_u8=True, kernel_events=ev)
         if timed:
-            events.append((ev0, ev1))
+            events.append(ev)
         return img
-
-    def untile_gathered():
-        cat = torch.cat(gathered, 0)
-        keep = [i for i, t in enumerate(gather_tiles) if not t.is_empty()]
-        tiles = [gather_tiles[i] for i in keep]
-        if len(keep) != len(gather_tiles):
-            cat = cat[torch.tensor(keep, device=dev)]
-        return full_fr.untile(cat.contiguous(), tiles, want_u8=True)
 
     def barrier():
         if world > 1:
@@ -169,7 +144,7 @@ def main():
         value = total_rays * args.steps / elapsed / 1e6
         # dominant kernel: render_tiles_kernel.  Algorithmic bytes per launch = B_ray x rays of this rank's launch
         # (DESIGN.md "Roofline"); duration from HIP events on the launch stream.
-        rays_per_launch = fr.rays_per_frame
+        rays_per_launch = frame.rays_per_frame_local
         achieved = rays_per_launch * B_RAY_DEPTH1 / (k_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
@@ -200,7 +175,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "render_tiles_kernel",
+                "kernel": "render_tiles_packet_kernel" if args.traversal == "packets" else "render_tiles_kernel",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -1,0 +1,109 @@
+"""Multi-GPU rendering: one process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm).
+
+screen_block tiles are the unit of work sharing in the reference (threads pull tiles from one queue,
+machinery.rs:74-105); here ranks own a static round-robin share of the row-major tile grid and every sample of a
+pixel stays on one device, so the per-pixel accumulation order -- and therefore the image -- is independent of the
+number of GPUs.  There is no collective on the data path; the only exchange is the final gather of the tile-major
+framebuffer shards to rank 0, followed by the un-tile kernel there.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+from .screen_block import ScreenBlock
+
+EMPTY = ScreenBlock(0, 0, 0, 0)
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    """Static partition of a tile list over `world` ranks."""
+
+    world: int
+    per_rank: int                      # tiles per shard, padded to equal size for the gather
+    shards: tuple                      # shards[r] = tiles of rank r (unpadded)
+
+    @property
+    def gather_order(self) -> List[ScreenBlock]:
+        """Tile of every slot of the rank-major concatenation of the padded shards (EMPTY = padding)."""
+        out: List[ScreenBlock] = []
+        for tl in self.shards:
+            out += list(tl) + [EMPTY] * (self.per_rank - len(tl))
+        return out
+
+    def keep_indices(self) -> List[int]:
+        return [i for i, t in enumerate(self.gather_order) if not t.is_empty()]
+
+
+def plan_shards(tiles: Sequence[ScreenBlock], world: int) -> ShardPlan:
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    shards = tuple(tuple(tiles[r::world]) for r in range(world))
+    per_rank = max((len(s) for s in shards), default=0)
+    return ShardPlan(world, per_rank, shards)
+
+
+def gather_shards(shard, plan: ShardPlan, rank: int, group=None, dst: int = 0):
+    """Gather equal-size tile-major shards [per_rank, ts, ts, 4] to `dst`.  Returns the rank-major concatenation
+    [world*per_rank, ts, ts, 4] on dst, None elsewhere.  With RCCL this is grouped send/recv: every peer uses its own
+    xGMI link to the root."""
+    import torch
+    import torch.distributed as dist
+
+    if plan.world == 1:
+        return shard
+    assert shard.shape[0] == plan.per_rank
+    bufs = [torch.empty_like(shard) for _ in range(plan.world)] if rank == dst else None
+    dist.gather(shard, bufs, dst=dst, group=group)
+    return torch.cat(bufs, 0) if rank == dst else None
+
+
+class DistributedFrame:
+    """Per-rank driver used by bench.py: render my shard in one launch, gather, un-tile on rank 0."""
+
+    def __init__(self, scene, camera, settings, rank: int, world: int, tiles: Optional[Sequence[ScreenBlock]] = None):
+        import torch
+
+        from .renderer import FrameRenderer
+        from .screen_block import tile_ordering
+
+        w, h = settings.resolution
+        self.rank, self.world, self.settings = rank, world, settings
+        self.all_tiles = list(tiles) if tiles is not None else tile_ordering(ScreenBlock(0, 0, w, h), settings.tile_size)
+        self.plan = plan_shards(self.all_tiles, world)
+        self.renderer = FrameRenderer(scene, camera, settings, tiles=self.plan.shards[rank])
+        ts = settings.tile_size
+        self.shard = torch.zeros((max(self.plan.per_rank, 1), ts, ts, 4), dtype=torch.float32, device=self.renderer.device)
+        self._keep = None
+        if rank == 0:
+            keep = self.plan.keep_indices()
+            self._tiles0 = [self.plan.gather_order[i] for i in keep]
+            if len(keep) != self.plan.world * self.plan.per_rank:
+                self._keep = torch.tensor(keep, device=self.renderer.device)
+
+    @property
+    def rays_per_frame_local(self) -> int:
+        return self.renderer.rays_per_frame
+
+    def render_local(self):
+        return self.renderer.render()
+
+    def step(self, want_u8: bool = True, kernel_events=None):
+        """One frame: returns (image f32, image u8) on rank 0, (None, None) elsewhere.  kernel_events = (start, end)
+        torch.cuda.Event pair recorded around the render launch on the current stream."""
+        if kernel_events is not None:
+            kernel_events[0].record()
+        buf = self.render_local()
+        if kernel_events is not None:
+            kernel_events[1].record()
+        if self.world == 1:
+            return self.renderer.untile(want_u8=want_u8)
+        n = len(self.plan.shards[self.rank])
+        self.shard[:n].copy_(buf[:n])
+        cat = gather_shards(self.shard, self.plan, self.rank)
+        if self.rank != 0:
+            return None, None
+        if self._keep is not None:
+            cat = cat.index_select(0, self._keep)
+        return self.renderer.untile(cat.contiguous(), self._tiles0, want_u8=want_u8)
