@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x5EED)
     ap.add_argument("--scene", default=os.path.join(ROOT, "tests", "golden", "teapot.obj"))
+    ap.add_argument("--detail", type=float, default=1.0, help="atrium tessellation (1.0 = 258 k triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-tile-stride", type=int, default=11, help="cpu_baseline renders every k-th tile")
     ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on cpu_baseline worker threads")
@@ -59,8 +60,20 @@ def cpu_baseline(args):
         pass
     # a one-GPU box's CPU share is 16 cores however many the host exposes; `cores` = the threads actually used
     cores = min(cores, args.cpu_threads)
-    b = po.Bvh.from_obj(args.scene)
-    s = po.build_sampler(po.teapot_camera(), args.width, args.height)
+    if args.scene == "atrium":
+        import ctypes as C
+
+        from minipath_amd import scenes
+
+        b = po.Bvh.build(*scenes.atrium(1, args.detail))
+        cam = po.Camera()
+        po.lib().mpo_camera_default(C.byref(cam))
+        po.lib().mpo_camera_look_at(C.byref(cam), po.vec3(-16.0, 4.2, 0.8), po.vec3(12.0, 5.5, -0.5), po.vec3(0, 1, 0))
+        cam.f_number = 4.0
+        s = po.build_sampler(cam, args.width, args.height)
+    else:
+        b = po.Bvh.from_obj(args.scene)
+        s = po.build_sampler(po.teapot_camera(), args.width, args.height)
     ntiles = len(po.tile_ordering(0, 0, args.width, args.height, args.tile))
     stride = max(1, args.cpu_tile_stride)
     _, _, secs, rays, _ = b.render_image_mt(s, args.width, args.height, args.spp, args.seed, args.tile, cores, 0, stride)
@@ -98,8 +111,14 @@ def main():
     from minipath_amd.distributed import DistributedFrame
 
     ctx = mp.Context(local_rank)
-    scene = mp.Scene(mp.TriangleBvh.with_obj(args.scene, ctx))
-    cam = mp.Camera.teapot_view()
+    if args.scene == "atrium":  # Sponza stand-in (BASELINE configs[2..4]; data/Sponza is an empty submodule)
+        from minipath_amd import scenes
+
+        scene = mp.Scene(mp.TriangleBvh.build(*scenes.atrium(1, args.detail), ctx))
+        cam = scenes.atrium_camera()
+    else:
+        scene = mp.Scene(mp.TriangleBvh.with_obj(args.scene, ctx))
+        cam = mp.Camera.teapot_view()
     st = mp.RenderSettings(args.tile, args.spp, (args.width, args.height), seed=args.seed, traversal=args.traversal)
     frame = DistributedFrame(scene, cam, st, rank, world)
     all_tiles = frame.all_tiles

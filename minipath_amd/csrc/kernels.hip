@@ -463,28 +463,78 @@ __device__ __forceinline__ float slab_entry(float bnx, float bny, float bnz, flo
     return t1;
 }
 
-template <bool PATCH_NAN>
-__device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, PacketHit& hit) {
+// Wave-uniform stack in registers: four VGPRs used as 64-entry arrays + a 64-bit stale mask in SGPRs.
+struct RegStack {
+    int link, src, mlo, mhi;
+    uint64_t stale;  // bit k: some lane's best.t changed after entry k was pushed
+    int lane;
+    __device__ __forceinline__ RegStack(float*, int lane_) : link(0), src(0), mlo(0), mhi(0), stale(0), lane(lane_) {}
+    __device__ __forceinline__ void push(int sp, uint32_t l, uint32_t s, uint64_t m) {
+        const bool slot = lane == sp;
+        link = slot ? static_cast<int>(l) : link;
+        src = slot ? static_cast<int>(s) : src;
+        mlo = slot ? static_cast<int>(static_cast<uint32_t>(m)) : mlo;
+        mhi = slot ? static_cast<int>(static_cast<uint32_t>(m >> 32)) : mhi;
+        stale &= ~(1ull << sp);
+    }
+    __device__ __forceinline__ void pop(int sp, uint32_t& l, uint32_t& s, uint64_t& m, bool& is_stale) const {
+        l = static_cast<uint32_t>(__builtin_amdgcn_readlane(link, sp));
+        s = static_cast<uint32_t>(__builtin_amdgcn_readlane(src, sp));
+        m = static_cast<uint32_t>(__builtin_amdgcn_readlane(mlo, sp)) |
+            (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(mhi, sp))) << 32);
+        is_stale = ((stale >> sp) & 1ull) != 0ull;
+    }
+    __device__ __forceinline__ void all_stale() { stale = ~0ull; }
+    __device__ __forceinline__ void sync() {}
+};
+
+// The same stack in LDS for trees deeper than 9 levels (7*depth+1 > 64): one uint4 {link, src, mask} + an epoch word
+// per entry, written by lane 0 and read back as a broadcast.
+struct LdsStack {
+    uint4* ent;
+    uint32_t* ep;
+    uint32_t epoch;
+    int lane;
+    __device__ __forceinline__ LdsStack(float* lds, int lane_) : ent(reinterpret_cast<uint4*>(lds)), ep(nullptr), epoch(0), lane(lane_) {}
+    __device__ __forceinline__ void bind(uint32_t cap) { ep = reinterpret_cast<uint32_t*>(ent + cap); }
+    __device__ __forceinline__ void push(int sp, uint32_t l, uint32_t s, uint64_t m) {
+        if (lane == 0) {
+            ent[sp] = make_uint4(l, s, static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32));
+            ep[sp] = epoch;
+        }
+    }
+    __device__ __forceinline__ void pop(int sp, uint32_t& l, uint32_t& s, uint64_t& m, bool& is_stale) const {
+        const uint4 e = ent[sp];
+        const uint32_t pe = ep[sp];
+        l = __builtin_amdgcn_readfirstlane(e.x);
+        s = __builtin_amdgcn_readfirstlane(e.y);
+        m = __builtin_amdgcn_readfirstlane(e.z) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(e.w)) << 32);
+        is_stale = __builtin_amdgcn_readfirstlane(pe) != epoch;
+    }
+    __device__ __forceinline__ void all_stale() { epoch++; }
+    __device__ __forceinline__ void sync() { wave_lds_sync(); }
+};
+
+template <bool PATCH_NAN, class Stack>
+__device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
     const int lane = static_cast<int>(threadIdx.x) & 63;
     kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
     kfp tris = (kfp)(uintptr_t)sc.tris_aos;
     kup nvalid = (kup)(uintptr_t)sc.pkt_valid;
     float best_t = FLT_MAX, bu = 0.0f, bv = 0.0f;  // best (:34-37)
     uint32_t bprim = kNoPrim;
-    // the stack (see above); entry 0 = root (:28-32), t1 = -inf: never culled
-    const uint64_t m0 = __ballot(active);
-    int st_link = static_cast<int>(sc.root), st_src = static_cast<int>(kSrcRoot);
-    int st_mlo = static_cast<int>(static_cast<uint32_t>(m0)), st_mhi = static_cast<int>(static_cast<uint32_t>(m0 >> 32));
-    uint64_t stale = 0;  // bit k: some lane's best.t changed after entry k was pushed
+    // entry 0 = root (:28-32), t1 = -inf: never culled
+    st.push(0, sc.root, kSrcRoot, __ballot(active));
+    st.sync();
     int sp = 1;
     while (sp > 0) {
         sp--;
-        const uint32_t link = static_cast<uint32_t>(__builtin_amdgcn_readlane(st_link, sp));
-        const uint32_t src = static_cast<uint32_t>(__builtin_amdgcn_readlane(st_src, sp));
-        const uint64_t pm = static_cast<uint32_t>(__builtin_amdgcn_readlane(st_mlo, sp)) |
-                            (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(st_mhi, sp))) << 32);
+        uint32_t link, src;
+        uint64_t pm;
+        bool is_stale;
+        st.pop(sp, link, src, pm, is_stale);
         bool on = ((pm >> lane) & 1ull) != 0ull;
-        if (((stale >> sp) & 1ull) != 0ull && src != kSrcRoot) {  // :40-44, per ray
+        if (is_stale && src != kSrcRoot) {  // :40-44, per ray
             kfp bx = nodes + static_cast<size_t>(src) * 8;
             const float node_t1 = slab_entry<PATCH_NAN>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], r);
             on = on && !(node_t1 > best_t);
@@ -503,15 +553,11 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                                 best_t, t1, t2);
                 const uint64_t okm = __ballot(on && (t1 <= t2));
                 if (okm != 0) {
-                    const bool slot = lane == sp;
-                    st_link = slot ? static_cast<int>(child) : st_link;
-                    st_src = slot ? static_cast<int>(node * 8u + c) : st_src;
-                    st_mlo = slot ? static_cast<int>(static_cast<uint32_t>(okm)) : st_mlo;
-                    st_mhi = slot ? static_cast<int>(static_cast<uint32_t>(okm >> 32)) : st_mhi;
-                    stale &= ~(1ull << sp);
+                    st.push(sp, child, node * 8u + c, okm);
                     sp++;
                 }
             }
+            st.sync();
         } else {
             // intersect_triangles :104-140 ; every lane walks the leaf's triangles in (packet, lane) order with a
             // strict `<`.  Padding (only at the tail of the last packet) can never be accepted and is not visited.
@@ -546,24 +592,26 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 }
                 v0x = n0; v0y = n1; v0z = n2; e1x = n3; e1y = n4; e1z = n5; e2x = n6; e2y = n7; e2z = n8;
             }
-            if (__ballot(changed) != 0) stale = ~0ull;  // every entry still on the stack predates this change
+            if (__ballot(changed) != 0) st.all_stale();  // every entry still on the stack predates this change
         }
     }
     hit.t = best_t; hit.u = bu; hit.v = bv; hit.prim = bprim;
 }
 
-__device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, PacketHit& hit) {
+template <class Stack>
+__device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
     const bool slow = active && (fabsf(r.ix) == INFINITY || fabsf(r.iy) == INFINITY || fabsf(r.iz) == INFINITY);
-    if (__ballot(slow) == 0) trace_packet_impl<false>(sc, r, active, hit);
-    else trace_packet_impl<true>(sc, r, active, hit);
+    if (__ballot(slow) == 0) trace_packet_impl<false>(sc, r, active, st, hit);
+    else trace_packet_impl<true>(sc, r, active, st, hit);
 }
 
 // Fused tile render on ray packets.  A wave owns a block of 64/S pixels and shoots S consecutive samples of each
 // pixel per pass (lane = pixel*S + sub-sample): all 64 rays of a pass are neighbours on the film, so the packet stays
 // coherent, while the work unit (block x all samples) shrinks with S, which evens out the load.  pixel_sum is
 // accumulated strictly in sample order (worker.rs:41-43) by the lane with sub-sample 0.
-template <int S>
+template <int S, bool LDS_STACK>
 __global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
     constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : (S <= 32) ? 2 : 1;  // pixel block = BW x BH, BW*BH*S == 64
     constexpr int BH = 64 / S / BW;
     const int lane = static_cast<int>(threadIdx.x) & 63;
@@ -593,7 +641,17 @@ __global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P
             const bool go = act && may_hit_scene(P.scene, r);
             PacketHit h;
             h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
-            if (__ballot(go) != 0) trace_packet(P.scene, r, go, h);
+            if (__ballot(go) != 0) {
+                float* lds = reinterpret_cast<float*>(smem + static_cast<size_t>(static_cast<int>(threadIdx.x) >> 6) * P.lds_per_wave);
+                if (LDS_STACK) {
+                    LdsStack st(lds, lane);
+                    st.bind(P.scene.stack_cap);
+                    trace_packet(P.scene, r, go, st, h);
+                } else {
+                    RegStack st(lds, lane);
+                    trace_packet(P.scene, r, go, st, h);
+                }
+            }
             float c = 0.0f;
             const bool hit = h.prim != kNoPrim;
             if (hit) {
@@ -778,23 +836,27 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);
         return check(hipGetLastError(), "render_tiles_kernel launch", err);
     }
-    if (L.scene.stack_cap > static_cast<uint32_t>(kPacketStackMax)) {  // deeper than 9 levels: use the group traversal
-        const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * 8));
-        hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);
-        return check(hipGetLastError(), "render_tiles_kernel launch", err);
-    }
     // samples of one pixel in flight per pass: 8 keeps the 64 rays of a pass within a 4x2 pixel footprint and makes
     // the work units 8x smaller than a whole 8x8 block (measured best on MI355X: profiles/r01_notes.md)
     int S = L.spp >= 8 ? 8 : L.spp >= 4 ? 4 : L.spp >= 2 ? 2 : 1;
     if (getenv("MP_S")) S = atoi(getenv("MP_S"));  // experiments only
-    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want * S, static_cast<uint64_t>(L.cu_count) * 8));
-    if (S == 2) hipLaunchKernelGGL(render_tiles_packet_kernel<2>, dim3(grid), dim3(256), 0, st, P);
-    else if (S == 4) hipLaunchKernelGGL(render_tiles_packet_kernel<4>, dim3(grid), dim3(256), 0, st, P);
-    else if (S == 8) hipLaunchKernelGGL(render_tiles_packet_kernel<8>, dim3(grid), dim3(256), 0, st, P);
-    else if (S == 16) hipLaunchKernelGGL(render_tiles_packet_kernel<16>, dim3(grid), dim3(256), 0, st, P);
-    else if (S == 32) hipLaunchKernelGGL(render_tiles_packet_kernel<32>, dim3(grid), dim3(256), 0, st, P);
-    else if (S == 64) hipLaunchKernelGGL(render_tiles_packet_kernel<64>, dim3(grid), dim3(256), 0, st, P);
-    else hipLaunchKernelGGL(render_tiles_packet_kernel<1>, dim3(grid), dim3(256), 0, st, P);
+    const bool lds_stack = L.scene.stack_cap > static_cast<uint32_t>(kPacketStackMax);
+    P.lds_per_wave = lds_stack ? L.scene.stack_cap * 20u + 12u & ~15u : 0u;
+    const uint32_t plds = P.lds_per_wave * 4;
+    if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
+    const uint32_t per_cu = plds ? std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds)) : 8u;
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want * S, static_cast<uint64_t>(L.cu_count) * per_cu));
+#define MP_LAUNCH_PACKET(SV)                                                                                         \
+    do {                                                                                                             \
+        if (lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<SV, true>), dim3(grid), dim3(256), plds, st, P);  \
+        else hipLaunchKernelGGL((render_tiles_packet_kernel<SV, false>), dim3(grid), dim3(256), 0, st, P);            \
+    } while (0)
+    if (S == 2) MP_LAUNCH_PACKET(2);
+    else if (S == 4) MP_LAUNCH_PACKET(4);
+    else if (S == 8) MP_LAUNCH_PACKET(8);
+    else if (S == 16) MP_LAUNCH_PACKET(16);
+    else MP_LAUNCH_PACKET(1);
+#undef MP_LAUNCH_PACKET
     return check(hipGetLastError(), "render_tiles_packet_kernel launch", err);
 }
 

@@ -168,7 +168,13 @@ class Builder {
         size_t cnt[3] = {to_usize(std::ceil(sx / bin_size)), to_usize(std::ceil(sy / bin_size)),
                          to_usize(std::ceil(sz / bin_size))};  // :429
         size_t nb = cnt[0] * cnt[1] * cnt[2];
-        if (nb == 0 || nb > (size_t{1} << 26)) { fail("degenerate centroid box: bin grid empty or too large (reference would panic)"); return 0; }
+        if (nb == 0 || nb > (size_t{1} << 26)) {
+            char msg[256];
+            std::snprintf(msg, sizeof msg, "degenerate centroid box (%zu triangles, centroid extent %g x %g x %g, bin grid %zu x %zu x %zu): the "
+                          "reference's BinGrid panics here (building.rs:424-429)", n, sx, sy, sz, cnt[0], cnt[1], cnt[2]);
+            fail(msg);
+            return 0;
+        }
 
         struct Bin { Box3 box; size_t count; size_t parent; };
         std::vector<Bin> bins(nb);

@@ -369,3 +369,37 @@ def test_render_synthetic_scenes(ctx, oracle, name, traversal):
     assert np.array_equal(bits(img.cpu().numpy()), bits(of))
     assert np.array_equal(img8.cpu().numpy(), ou8)
     assert (of[..., 3] > 0).mean() > 0.05
+
+
+@pytest.mark.parametrize("traversal", ["packets", "groups"])
+def test_atrium_deep_tree(ctx, oracle, traversal):
+    """Sponza stand-in (minipath_amd.scenes.atrium) at 5 % detail: 13 k triangles, 10 inner levels => traversal stack
+    bound 71 > 64, i.e. the LDS variant of the packet stack; camera inside the hall (every ray hits something)."""
+    import ctypes as C
+
+    from minipath_amd import scenes
+
+    pos, nrm, tex, tri = scenes.atrium(1, 0.05)
+    bvh = mp.TriangleBvh.build(pos, nrm, tex, tri, ctx)
+    assert 7 * bvh.info().depth + 1 > 64
+    scene = mp.Scene(bvh)
+    orc = oracle.Bvh.build(pos, nrm, tex, tri)
+    cam = scenes.atrium_camera()
+    oc = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(oc))
+    oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(-16.0, 4.2, 0.8), oracle.vec3(12.0, 5.5, -0.5), oracle.vec3(0, 1, 0))
+    oc.f_number = 4.0
+    res = (160, 96)
+    assert np.array_equal(bits(cam.build_sampler(res).as_array()), bits(oracle.build_sampler(oc, *res).as_array()))
+    st = mp.RenderSettings(32, 9, res, seed=3, traversal=traversal)
+    fr = mp.FrameRenderer(scene, cam, st)
+    fr.render()
+    img, img8 = fr.untile()
+    of, ou8, *_ = orc.render_image_mt(oracle.build_sampler(oc, *res), res[0], res[1], 9, 3, 32, 8)
+    assert np.array_equal(bits(img.cpu().numpy()), bits(of))
+    assert np.array_equal(img8.cpu().numpy(), ou8)
+    assert (of[..., 3] > 0).mean() > 0.95
+    bmin, bmax = orc.bbox()
+    o, d = meshes.random_rays(20000, 5, bmin, bmax)
+    got, exp = _trace_both(scene, orc, o, d)
+    _assert_hits_equal(got, exp)
