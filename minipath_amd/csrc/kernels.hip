@@ -485,38 +485,51 @@ struct RegStack {
         is_stale = ((stale >> sp) & 1ull) != 0ull;
     }
     __device__ __forceinline__ void all_stale() { stale = ~0ull; }
-    __device__ __forceinline__ void sync() {}
+    __device__ __forceinline__ void sync(int) {}
 };
 
-// The same stack in LDS for trees deeper than 9 levels (7*depth+1 > 64): one uint4 {link, src, mask} + an epoch word
-// per entry, written by lane 0 and read back as a broadcast.
-struct LdsStack {
+// Trees deeper than 9 levels (7*depth+1 > 64) can in principle need more entries: those above 63 go to LDS (one uint4
+// {link, src, mask} + an epoch word per entry, written by lane 0, read back as a broadcast).  Real walks rarely get there
+// (the 28-level atrium tree peaks at 16 entries per ray), so the register path stays the common one.
+struct HybridStack {
+    RegStack reg;
     uint4* ent;
     uint32_t* ep;
     uint32_t epoch;
-    int lane;
-    __device__ __forceinline__ LdsStack(float* lds, int lane_) : ent(reinterpret_cast<uint4*>(lds)), ep(nullptr), epoch(0), lane(lane_) {}
-    __device__ __forceinline__ void bind(uint32_t cap) { ep = reinterpret_cast<uint32_t*>(ent + cap); }
+    __device__ __forceinline__ HybridStack(float* lds, int lane_, uint32_t cap)
+        : reg(nullptr, lane_), ent(reinterpret_cast<uint4*>(lds)), ep(nullptr), epoch(0) {
+        ep = reinterpret_cast<uint32_t*>(ent + (cap > 64u ? cap - 64u : 0u));
+    }
     __device__ __forceinline__ void push(int sp, uint32_t l, uint32_t s, uint64_t m) {
-        if (lane == 0) {
-            ent[sp] = make_uint4(l, s, static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32));
-            ep[sp] = epoch;
+        if (sp < kPacketStackMax) {
+            reg.push(sp, l, s, m);
+        } else if (reg.lane == 0) {
+            ent[sp - kPacketStackMax] = make_uint4(l, s, static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32));
+            ep[sp - kPacketStackMax] = epoch;
         }
     }
     __device__ __forceinline__ void pop(int sp, uint32_t& l, uint32_t& s, uint64_t& m, bool& is_stale) const {
-        const uint4 e = ent[sp];
-        const uint32_t pe = ep[sp];
-        l = __builtin_amdgcn_readfirstlane(e.x);
-        s = __builtin_amdgcn_readfirstlane(e.y);
-        m = __builtin_amdgcn_readfirstlane(e.z) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(e.w)) << 32);
-        is_stale = __builtin_amdgcn_readfirstlane(pe) != epoch;
+        if (sp < kPacketStackMax) {
+            reg.pop(sp, l, s, m, is_stale);
+        } else {
+            const uint4 e = ent[sp - kPacketStackMax];
+            const uint32_t pe = ep[sp - kPacketStackMax];
+            l = __builtin_amdgcn_readfirstlane(e.x);
+            s = __builtin_amdgcn_readfirstlane(e.y);
+            m = __builtin_amdgcn_readfirstlane(e.z) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(e.w)) << 32);
+            is_stale = __builtin_amdgcn_readfirstlane(pe) != epoch;
+        }
     }
-    __device__ __forceinline__ void all_stale() { epoch++; }
-    __device__ __forceinline__ void sync() { wave_lds_sync(); }
+    __device__ __forceinline__ void all_stale() { reg.all_stale(); epoch++; }
+    __device__ __forceinline__ void sync(int sp) { if (sp > kPacketStackMax) wave_lds_sync(); }
 };
 
-template <bool PATCH_NAN, class Stack>
+// MODE 1: every active ray has finite inverse directions (no 0*inf, so the NaN patches of aabb.rs:262-267 are dead code).
+// MODE 2: literal aabb.rs:254-284.  (A third variant that ordered each child's planes by a wave-uniform ray octant and dropped
+// the min/max was measured and rejected: +13 VGPRs, no gain -- profiles/r01_notes.md.)
+template <int MODE, class Stack>
 __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
+    constexpr bool PATCH_NAN = MODE == 2;
     const int lane = static_cast<int>(threadIdx.x) & 63;
     kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
     kfp tris = (kfp)(uintptr_t)sc.tris_aos;
@@ -525,7 +538,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
     uint32_t bprim = kNoPrim;
     // entry 0 = root (:28-32), t1 = -inf: never culled
     st.push(0, sc.root, kSrcRoot, __ballot(active));
-    st.sync();
+    st.sync(1);
     int sp = 1;
     while (sp > 0) {
         sp--;
@@ -549,15 +562,15 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 const uint32_t child = __builtin_amdgcn_readfirstlane(as_u(nd[c * 8 + 6]));
                 if (child == MP_LINK_NULL) continue;
                 float t1, t2;
-                slab<PATCH_NAN>(nd[c * 8 + 0], nd[c * 8 + 1], nd[c * 8 + 2], nd[c * 8 + 3], nd[c * 8 + 4], nd[c * 8 + 5], r,
-                                best_t, t1, t2);
+                slab<PATCH_NAN>(nd[c * 8 + 0], nd[c * 8 + 1], nd[c * 8 + 2], nd[c * 8 + 3], nd[c * 8 + 4], nd[c * 8 + 5], r, best_t,
+                                t1, t2);
                 const uint64_t okm = __ballot(on && (t1 <= t2));
                 if (okm != 0) {
                     st.push(sp, child, node * 8u + c, okm);
                     sp++;
                 }
             }
-            st.sync();
+            st.sync(sp);
         } else {
             // intersect_triangles :104-140 ; every lane walks the leaf's triangles in (packet, lane) order with a
             // strict `<`.  Padding (only at the tail of the last packet) can never be accepted and is not visited.
@@ -601,8 +614,8 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
 template <class Stack>
 __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
     const bool slow = active && (fabsf(r.ix) == INFINITY || fabsf(r.iy) == INFINITY || fabsf(r.iz) == INFINITY);
-    if (__ballot(slow) == 0) trace_packet_impl<false>(sc, r, active, st, hit);
-    else trace_packet_impl<true>(sc, r, active, st, hit);
+    if (__ballot(slow) == 0) trace_packet_impl<1>(sc, r, active, st, hit);
+    else trace_packet_impl<2>(sc, r, active, st, hit);
 }
 
 // Fused tile render on ray packets.  A wave owns a block of 64/S pixels and shoots S consecutive samples of each
@@ -644,8 +657,7 @@ __global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P
             if (__ballot(go) != 0) {
                 float* lds = reinterpret_cast<float*>(smem + static_cast<size_t>(static_cast<int>(threadIdx.x) >> 6) * P.lds_per_wave);
                 if (LDS_STACK) {
-                    LdsStack st(lds, lane);
-                    st.bind(P.scene.stack_cap);
+                    HybridStack st(lds, lane, P.scene.stack_cap);
                     trace_packet(P.scene, r, go, st, h);
                 } else {
                     RegStack st(lds, lane);
@@ -841,7 +853,7 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     int S = L.spp >= 8 ? 8 : L.spp >= 4 ? 4 : L.spp >= 2 ? 2 : 1;
     if (getenv("MP_S")) S = atoi(getenv("MP_S"));  // experiments only
     const bool lds_stack = L.scene.stack_cap > static_cast<uint32_t>(kPacketStackMax);
-    P.lds_per_wave = lds_stack ? L.scene.stack_cap * 20u + 12u & ~15u : 0u;
+    P.lds_per_wave = lds_stack ? ((L.scene.stack_cap - 64u) * 20u + 15u) & ~15u : 0u;
     const uint32_t plds = P.lds_per_wave * 4;
     if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
     const uint32_t per_cu = plds ? std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds)) : 8u;
