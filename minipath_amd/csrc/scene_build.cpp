@@ -4,19 +4,26 @@
 // kernels read are the ones the reference's TriangleBvh would hold (triangle geometry is quantised
 // against the decompressed box chain, so the builder has to be reproduced, not just "a BVH").
 //
-// Structure differs from the reference on purpose: the greedy bin merge (building.rs:278-293, 394-414) keeps a
-// pairwise-improvement matrix and a per-packet-count cost table, so a merge costs O(groups) SAH evaluations
-// instead of O(groups^2); the scan order and the strict `>` tie-break of find_best_bin_merge are preserved, so
-// the chosen pairs -- and therefore the tree -- are identical.
+// Structure differs from the reference on purpose ("builder acceleration"):
+//  * the greedy bin merge (building.rs:278-293, 394-414) keeps a pairwise-improvement matrix, per-row cached maxima and
+//    a per-packet-count cost table, so a merge costs O(groups) SAH evaluations and (mostly) O(groups) comparisons
+//    instead of O(groups^2) SAH evaluations; the scan order and the strict `>` tie-break of find_best_bin_merge are
+//    preserved, so the chosen pairs -- and therefore the tree -- are identical;
+//  * subtrees are built as independently numbered fragments, large ones on other threads, and spliced into the parent
+//    in child order, which restores the reference's pre-order node / DFS packet numbering.
 //
 // All arithmetic is f32 and must not be contracted (-ffp-contract=off); fmaf only where the reference writes
 // mul_add (compressed_geometry.rs:103-109).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <future>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <unordered_map>
 
 #include "mp_internal.h"
@@ -83,33 +90,71 @@ inline size_t to_usize(float x) {  // Rust `as usize`
     return static_cast<size_t>(x);
 }
 
+// One subtree, numbered from 0 (inner nodes in pre-order, packets in DFS order) so that subtrees can be built
+// independently -- on different threads -- and spliced into their parent afterwards by offsetting the links.
+struct Fragment {
+    std::vector<InnerNodeRef> inner;
+    std::vector<Box3> inner_box;
+    std::vector<TriPacketRef> packets;
+    std::vector<Box3> packet_box;
+    std::vector<TriShadingRef> shading;
+    uint32_t depth = 0;  // inner levels below (and including) this subtree's root
+    uint32_t root = MP_LINK_NULL;
+};
+
 class Builder {
   public:
-    Builder(const float* pos, const float* nrm, uint32_t nv, HostBvh& out, std::string& err)
-        : pos_(pos), nrm_(nrm), out_(out), err_(err) { (void)nv; }
+    Builder(const float* pos, const float* nrm, uint32_t nt, std::string& err) : pos_(pos), nrm_(nrm), err_(err) {
+        // SplittingBin::sah cost factor per packet count (building.rs:358-383); read-only once built
+        const size_t max_pc = (static_cast<size_t>(nt) + kPacket - 1) / kPacket;
+        packet_cost_.resize(max_pc + 1);
+        for (size_t p = 0; p <= max_pc; p++) {
+            const float B = 8.0f;
+            float leaf_cost = (p <= 7) ? 0.75f * static_cast<float>(p) : std::numeric_limits<float>::infinity();
+            float pf = static_cast<float>(p);
+            float depth = std::floor(std::log(pf) / std::log(B));
+            float pw = 1.0f;
+            for (int i = 0; i < static_cast<int>(depth); i++) pw *= B;
+            float tree_cost = 1.0f * depth + 0.75f * std::ceil(pf / pw);
+            packet_cost_[p] = std::fmin(leaf_cost, tree_cost);
+        }
+        unsigned hw = std::thread::hardware_concurrency();
+        max_tasks_ = static_cast<int>(std::min(16u, hw ? hw : 1u)) - 1;
+    }
 
-    bool run(std::vector<Tri>& tris) {
+    bool run(std::vector<Tri>& tris, HostBvh& out) {
         Box3 bb;
         for (int k = 0; k < 3; k++) bb.mn[k] = bb.mx[k] = pos_[3 * tris[0].v[0] + k];
         for (const Tri& t : tris)
             for (int v = 0; v < 3; v++) extend(bb, &pos_[3 * t.v[v]]);
-        out_.bbox = bb;
-        out_.triangle_count = static_cast<uint32_t>(tris.size());
-        out_.root = recurse(tris.data(), tris.size(), bb, 0);
-        return !failed_;
+        Fragment f = recurse(tris.data(), tris.size(), bb);
+        if (failed_.load()) return false;
+        out.bbox = bb;
+        out.triangle_count = static_cast<uint32_t>(tris.size());
+        out.root = f.root;
+        out.depth = f.depth;
+        out.inner = std::move(f.inner);
+        out.inner_box = std::move(f.inner_box);
+        out.packets = std::move(f.packets);
+        out.packet_box = std::move(f.packet_box);
+        out.shading = std::move(f.shading);
+        return true;
     }
 
   private:
     const float* pos_;
     const float* nrm_;
-    HostBvh& out_;
     std::string& err_;
-    bool failed_ = false;
-    std::vector<float> packet_cost_;  // SplittingBin::sah cost factor per packet count (building.rs:358-383)
+    std::mutex err_mu_;
+    std::atomic<bool> failed_{false};
+    std::vector<float> packet_cost_;
+    std::atomic<int> live_tasks_{0};
+    int max_tasks_ = 0;
 
     void fail(const char* msg) {
-        if (!failed_) err_ = msg;
-        failed_ = true;
+        std::lock_guard<std::mutex> lk(err_mu_);
+        if (!failed_.load()) err_ = msg;
+        failed_.store(true);
     }
 
     void centroid(const Tri& t, float c[3]) const {  // triangle.rs:115-120
@@ -121,26 +166,7 @@ class Builder {
         }
     }
 
-    // cost factor of SplittingBin::sah for a given triangle count; area is multiplied in by the caller
-    float cost_for_count(size_t count) {
-        size_t pc = (count + kPacket - 1) / kPacket;
-        if (pc >= packet_cost_.size()) {
-            size_t old = packet_cost_.size();
-            packet_cost_.resize(pc + 1);
-            for (size_t p = old; p <= pc; p++) {
-                const float B = 8.0f;
-                float leaf_cost = (p <= 7) ? 0.75f * static_cast<float>(p) : std::numeric_limits<float>::infinity();
-                float pf = static_cast<float>(p);
-                float depth = std::floor(std::log(pf) / std::log(B));
-                float pw = 1.0f;
-                for (int i = 0; i < static_cast<int>(depth); i++) pw *= B;
-                float tree_cost = 1.0f * depth + 0.75f * std::ceil(pf / pw);
-                packet_cost_[p] = std::fmin(leaf_cost, tree_cost);
-            }
-        }
-        return packet_cost_[pc];
-    }
-    float sah(const Box3& b, size_t count) { return surface_area(b) * cost_for_count(count); }
+    float sah(const Box3& b, size_t count) const { return surface_area(b) * packet_cost_[(count + kPacket - 1) / kPacket]; }
 
     struct Group {
         Box3 box;
@@ -199,7 +225,12 @@ class Builder {
                                   static_cast<uint32_t>(groups.size())});
         if (groups.size() < 2) { fail("all centroids in a single bin (reference asserts groups.len() >= 2, building.rs:275)"); return 0; }
 
-        // improvement matrix: imp[a*G+b] = sah(a) + sah(b) - sah(a u b); symmetric in exact float arithmetic
+        // Greedy merge (building.rs:278-293) with find_best_bin_merge's result (:394-414: first maximum in the i1<i2 scan
+        // order, strict `>`) reproduced from cached data instead of an O(groups^2) SAH scan per merge:
+        //   imp[a*G+b]  = sah(a) + sah(b) - sah(a u b) by group id, symmetric in exact float arithmetic;
+        //   row_best[i] = first maximum of row i over the positions j > i.
+        // A merge rewrites position b1 and moves the last position into b2; only rows whose cached maximum sat at one
+        // of the touched positions are rescanned, the others are patched by comparing the (at most two) changed entries.
         const size_t G = groups.size();
         std::vector<float> imp(G * G, 0.0f);
         auto pair_improvement = [&](const Group& a, const Group& b) {
@@ -212,18 +243,29 @@ class Builder {
                 imp[i * G + j] = v;
                 imp[j * G + i] = v;
             }
-
-        while (groups.size() > 2) {  // :278-293
-            size_t ng = groups.size(), b1 = 0, b2 = 0;
-            float best = -inf;
-            for (size_t i1 = 0; i1 < ng; i1++) {  // find_best_bin_merge scan order :398-411
-                const float* row = &imp[static_cast<size_t>(groups[i1].id) * G];
-                for (size_t i2 = i1 + 1; i2 < ng; i2++) {
-                    float v = row[groups[i2].id];
-                    if (v > best) { b1 = i1; b2 = i2; best = v; }
-                }
+        struct RowBest { float v; size_t j; };
+        std::vector<RowBest> row_best(G);
+        auto at = [&](size_t i, size_t j) { return imp[static_cast<size_t>(groups[i].id) * G + groups[j].id]; };
+        auto rescan = [&](size_t i) {
+            RowBest rb{-inf, i};
+            const size_t ng = groups.size();
+            const float* row = &imp[static_cast<size_t>(groups[i].id) * G];
+            for (size_t j = i + 1; j < ng; j++) {
+                float v = row[groups[j].id];
+                if (v > rb.v) rb = {v, j};
             }
+            row_best[i] = rb;
+        };
+        for (size_t i = 0; i < G; i++) rescan(i);
+
+        while (groups.size() > 2) {
+            const size_t ng = groups.size();
+            size_t b1 = 0, b2 = 0;
+            float best = -inf;
+            for (size_t i1 = 0; i1 + 1 < ng; i1++)
+                if (row_best[i1].v > best) { best = row_best[i1].v; b1 = i1; b2 = row_best[i1].j; }
             if (best < 0.0f && ng <= kChildren) break;
+            const size_t last = ng - 1;
             Group& g1 = groups[b1];
             const Group& g2 = groups[b2];
             bins[g2.parent].parent = g1.parent;
@@ -237,6 +279,18 @@ class Builder {
                 float v = pair_improvement(groups[b1], groups[j]);
                 imp[static_cast<size_t>(merged.id) * G + groups[j].id] = v;
                 imp[static_cast<size_t>(groups[j].id) * G + merged.id] = v;
+            }
+            const size_t ng2 = groups.size();
+            auto patch = [&](size_t i, size_t j) {  // entry (i, j), j > i, has a new value
+                float v = at(i, j);
+                RowBest& rb = row_best[i];
+                if (v > rb.v || (v == rb.v && j < rb.j)) rb = {v, j};
+            };
+            for (size_t i = 0; i + 1 < ng2; i++) {
+                const size_t oj = row_best[i].j;
+                if (i == b1 || i == b2 || oj == b1 || oj == b2 || oj == last) { rescan(i); continue; }
+                if (i < b1) patch(i, b1);
+                if (i < b2 && b2 < ng2) patch(i, b2);
             }
         }
 
@@ -275,19 +329,18 @@ class Builder {
     }
 
     // building.rs:109-120
-    uint32_t recurse(Tri* tris, size_t n, const Box3& enc, uint32_t depth) {
-        if (failed_) return MP_LINK_NULL;
-        return n <= kLeafMaxTris ? leaf(tris, n, enc) : inner(tris, n, enc, depth);
+    Fragment recurse(Tri* tris, size_t n, const Box3& enc) {
+        if (failed_.load()) return Fragment{};
+        return n <= kLeafMaxTris ? leaf(tris, n, enc) : inner(tris, n, enc);
     }
 
     // building.rs:170-207
-    uint32_t leaf(const Tri* tris, size_t n, const Box3& enc) {
-        if (n == 0) { fail("empty leaf (reference asserts !triangles.is_empty(), building.rs:178)"); return MP_LINK_NULL; }
+    Fragment leaf(const Tri* tris, size_t n, const Box3& enc) {
+        Fragment f;
+        if (n == 0) { fail("empty leaf (reference asserts !triangles.is_empty(), building.rs:178)"); return f; }
         float size[3];
         for (int k = 0; k < 3; k++) size[k] = enc.mx[k] - enc.mn[k];  // aabb.rs:292-303
         size_t packets = (n + kPacket - 1) / kPacket;
-        size_t first = out_.packets.size();
-        if (first + packets - 1 > kMaxIndex) { fail("leaf link out of range"); return MP_LINK_NULL; }
         for (size_t p = 0; p < packets; p++) {
             TriPacketRef pk{};
             for (size_t lane = 0; lane < kPacket; lane++) {
@@ -306,25 +359,31 @@ class Builder {
                         sh.vi[v] = tris[ti].v[v];
                     }
                 }
-                out_.shading.push_back(sh);
+                f.shading.push_back(sh);
             }
-            out_.packets.push_back(pk);
-            out_.packet_box.push_back(enc);
+            f.packets.push_back(pk);
+            f.packet_box.push_back(enc);
         }
-        return static_cast<uint32_t>(first) << 3 | static_cast<uint32_t>(packets);  // new_leaf mod.rs:70-74
+        f.root = static_cast<uint32_t>(packets);  // new_leaf(index 0, count) mod.rs:70-74, index offset by the parent
+        return f;
+    }
+
+    static void offset_links(Fragment& f, uint32_t inner_off, uint32_t packet_off) {
+        auto fix = [&](uint32_t& link) {
+            if (link == MP_LINK_NULL) return;
+            link += ((link & 7u) == 0u ? inner_off : packet_off) << 3;
+        };
+        for (InnerNodeRef& nd : f.inner)
+            for (uint32_t& l : nd.link) fix(l);
+        fix(f.root);
     }
 
     // building.rs:122-168
-    uint32_t inner(Tri* tris, size_t n, const Box3& enc, uint32_t depth) {
+    Fragment inner(Tri* tris, size_t n, const Box3& enc) {
+        Fragment f;
         Child ch[8];
         int nchild = split(tris, n, ch);
-        if (failed_ || nchild <= 0) return MP_LINK_NULL;
-        size_t index = out_.inner.size();
-        if (index > kMaxIndex) { fail("inner link out of range"); return MP_LINK_NULL; }
-        out_.inner.emplace_back();  // placeholder :130-131 (pre-order numbering)
-        out_.inner_box.push_back(enc);
-        out_.depth = std::max(out_.depth, depth + 1);
-
+        if (failed_.load() || nchild <= 0) return f;
         float size[3];
         for (int k = 0; k < 3; k++) size[k] = enc.mx[k] - enc.mn[k];
         InnerNodeRef node{};
@@ -342,12 +401,43 @@ class Builder {
             }
             node.link[i] = MP_LINK_NULL;
         }
+        // children are independent: large ones go to other threads, the numbering is restored when they are spliced
+        Fragment sub[8];
+        std::future<Fragment> fut[8];
         for (int i = 0; i < nchild; i++) {
-            node.link[i] = recurse(tris + ch[i].lo, ch[i].hi - ch[i].lo, dec[i], depth + 1);
-            if (failed_) return MP_LINK_NULL;
+            const size_t cn = ch[i].hi - ch[i].lo;
+            if (cn >= 4096 && live_tasks_.fetch_add(1) < max_tasks_) {
+                fut[i] = std::async(std::launch::async, [this, tris, &ch, &dec, i, cn]() {
+                    Fragment r = recurse(tris + ch[i].lo, cn, dec[i]);
+                    live_tasks_.fetch_sub(1);
+                    return r;
+                });
+            } else {
+                if (cn >= 4096) live_tasks_.fetch_sub(1);
+                sub[i] = recurse(tris + ch[i].lo, cn, dec[i]);
+            }
         }
-        out_.inner[index] = node;
-        return static_cast<uint32_t>(index) << 3;  // new_inner mod.rs:77-80
+        for (int i = 0; i < nchild; i++)
+            if (fut[i].valid()) sub[i] = fut[i].get();
+        if (failed_.load()) return Fragment{};
+        f.inner.push_back(node);  // pre-order: this node is index 0 of its fragment (placeholder :130-131)
+        f.inner_box.push_back(enc);
+        for (int i = 0; i < nchild; i++) {
+            Fragment& c = sub[i];
+            const size_t io = f.inner.size(), po = f.packets.size();
+            if (io + c.inner.size() > kMaxIndex || po + c.packets.size() > kMaxIndex) { fail("link index out of range"); return Fragment{}; }
+            offset_links(c, static_cast<uint32_t>(io), static_cast<uint32_t>(po));
+            f.inner[0].link[i] = c.root;
+            f.inner.insert(f.inner.end(), c.inner.begin(), c.inner.end());
+            f.inner_box.insert(f.inner_box.end(), c.inner_box.begin(), c.inner_box.end());
+            f.packets.insert(f.packets.end(), c.packets.begin(), c.packets.end());
+            f.packet_box.insert(f.packet_box.end(), c.packet_box.begin(), c.packet_box.end());
+            f.shading.insert(f.shading.end(), c.shading.begin(), c.shading.end());
+            f.depth = std::max(f.depth, c.depth);
+        }
+        f.depth += 1;
+        f.root = 0;  // new_inner(index 0) mod.rs:77-80
+        return f;
     }
 };
 
@@ -367,8 +457,8 @@ int build_bvh(const float* pos, const float* nrm, const float* tex, uint32_t nv,
     if (tex) std::memcpy(out.vtex.data(), tex, static_cast<size_t>(nv) * 12);
     std::vector<Tri> tris(nt);
     std::memcpy(tris.data(), tri, static_cast<size_t>(nt) * sizeof(Tri));
-    Builder b(pos, out.vnormal.data(), nv, out, err);
-    if (!b.run(tris)) return MP_ERR_BUILD;
+    Builder b(pos, out.vnormal.data(), nt, err);
+    if (!b.run(tris, out)) return MP_ERR_BUILD;
     return MP_OK;
 }
 
