@@ -1,0 +1,59 @@
+"""Image output.  The reference renders into an `image::RgbaImage` and never writes it
+(src/cli.rs:33-46 drops the result); this is the missing last step: RGBA8 PNG and float PFM writers, stdlib only."""
+from __future__ import annotations
+
+import struct
+import zlib
+
+import numpy as np
+
+
+def save_png(path: str, rgba_u8: np.ndarray) -> None:
+    """Write an [h, w, 4] uint8 image (RenderProgress.image()) as an 8-bit RGBA PNG."""
+    img = np.ascontiguousarray(rgba_u8, dtype=np.uint8)
+    if img.ndim != 3 or img.shape[2] != 4:
+        raise ValueError("expected an [h, w, 4] uint8 image")
+    h, w, _ = img.shape
+    raw = np.zeros((h, w * 4 + 1), np.uint8)  # filter type 0 per scanline
+    raw[:, 1:] = img.reshape(h, w * 4)
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n")
+        f.write(chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)))
+        f.write(chunk(b"IDAT", zlib.compress(raw.tobytes(), 6)))
+        f.write(chunk(b"IEND", b""))
+
+
+def load_png_rgba8(path: str) -> np.ndarray:
+    """Reader for the files save_png writes (filter 0, 8-bit RGBA, single IDAT stream): round-trip tests."""
+    data = open(path, "rb").read()
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG")
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        (n,) = struct.unpack(">I", data[pos:pos + 4])
+        tag = data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        if tag == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            if depth != 8 or ctype != 6:
+                raise ValueError("only 8-bit RGBA")
+        elif tag == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, w * 4 + 1)
+    if np.any(raw[:, 0] != 0):
+        raise ValueError("only filter type 0")
+    return raw[:, 1:].reshape(h, w, 4).copy()
+
+
+def save_pfm(path: str, rgb_f32: np.ndarray) -> None:
+    """Write the pre-quantisation f32 means (RenderProgress.image_f32()[..., :3]) as a little-endian PFM."""
+    img = np.ascontiguousarray(rgb_f32[..., :3], dtype="<f4")
+    h, w, _ = img.shape
+    with open(path, "wb") as f:
+        f.write(f"PF\n{w} {h}\n-1.0\n".encode())
+        f.write(img[::-1].tobytes())  # PFM stores the bottom scanline first
