@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B_RAY_DEPTH1 = 136  # algorithmic HBM bytes per ray segment of the depth-1 wavefront formulation
+B_RAY_BOUNCE = 320  # compacted wavefront bounce mode (build-defined path extension, --depth N)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -44,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-tile-stride", type=int, default=11, help="cpu_baseline renders every k-th tile")
     ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on cpu_baseline worker threads")
     ap.add_argument("--traversal", default="packets", choices=["packets", "groups"])
+    ap.add_argument("--depth", type=int, default=0, help="0 = reference semantics (default); N >= 1 = build-defined path extension with at most N segments")
     ap.add_argument("--check", action="store_true", help="compare a few tiles of the GPU frame with the oracle")
     return ap.parse_args()
 
@@ -76,7 +78,10 @@ def cpu_baseline(args):
         s = po.build_sampler(po.teapot_camera(), args.width, args.height)
     ntiles = len(po.tile_ordering(0, 0, args.width, args.height, args.tile))
     stride = max(1, args.cpu_tile_stride)
-    _, _, secs, rays, _ = b.render_image_mt(s, args.width, args.height, args.spp, args.seed, args.tile, cores, 0, stride)
+    if args.depth > 0:
+        _, _, secs, rays = b.render_image_paths_mt(s, args.width, args.height, args.spp, args.seed, args.depth, args.tile, cores, 0, stride)
+    else:
+        _, _, secs, rays, _ = b.render_image_mt(s, args.width, args.height, args.spp, args.seed, args.tile, cores, 0, stride)
     return {
         "value": rays / secs / 1e6,
         "unit": "Mrays/s",
@@ -119,7 +124,7 @@ def main():
     else:
         scene = mp.Scene(mp.TriangleBvh.with_obj(args.scene, ctx))
         cam = mp.Camera.teapot_view()
-    st = mp.RenderSettings(args.tile, args.spp, (args.width, args.height), seed=args.seed, traversal=args.traversal)
+    st = mp.RenderSettings(args.tile, args.spp, (args.width, args.height), seed=args.seed, traversal=args.traversal, max_depth=args.depth)
     frame = DistributedFrame(scene, cam, st, rank, world)
     all_tiles = frame.all_tiles
     total_rays = args.width * args.height * args.spp
@@ -158,13 +163,27 @@ def main():
     else:
         k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
 
+    # rays = Object::intersect calls: W*H*spp for the reference semantics, traced path segments for --depth N
+    seg_local = int(frame.renderer.segments.item())
+    if world > 1:
+        segt = torch.tensor([seg_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(segt, op=dist.ReduceOp.SUM)
+        seg_total = int(segt.item())
+    else:
+        seg_total = seg_local
+    if args.depth == 0:
+        assert seg_total == total_rays, (seg_total, total_rays)
+    total_samples = total_rays
+    total_rays = seg_total
+    b_ray = B_RAY_BOUNCE if args.depth > 0 else B_RAY_DEPTH1
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_rays * args.steps / elapsed / 1e6
         # dominant kernel: render_tiles_kernel.  Algorithmic bytes per launch = B_ray x rays of this rank's launch
         # (DESIGN.md "Roofline"); duration from HIP events on the launch stream.
-        rays_per_launch = frame.rays_per_frame_local
-        achieved = rays_per_launch * B_RAY_DEPTH1 / (k_ms * 1e-3) / 1e9
+        rays_per_launch = seg_local
+        achieved = rays_per_launch * b_ray / (k_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
@@ -185,23 +204,25 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "samples_per_s": total_rays * args.steps / elapsed,
+            "samples_per_s": total_samples * args.steps / elapsed,
             "config": {
                 "workload": f"{os.path.basename(args.scene)} {args.width}x{args.height} {args.spp}spp tile{args.tile} "
-                            f"seed{args.seed:#x} depth1 (reference semantics: primary ray + |d.n|, worker.rs:51-66)",
+                            f"seed{args.seed:#x} " + ("depth1 (reference semantics: primary ray + |d.n|, worker.rs:51-66)" if args.depth == 0 else
+                                                     f"paths max_depth {args.depth} (build-defined extension, no reference counterpart; rays = traced segments)"),
                 "rays_per_step": total_rays,
                 "parallelism": f"tiles round-robin over {world} rank(s)" + (" + RCCL gather to rank 0" if world > 1 else ""),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "render_tiles_packet_kernel" if args.traversal == "packets" else "render_tiles_kernel",
+                "kernel": "render_paths_kernel" if args.depth > 0 else ("render_tiles_packet_kernel" if args.traversal == "packets" else "render_tiles_kernel"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "kernel_ms": k_ms,
-                "algorithmic_bytes_per_launch": rays_per_launch * B_RAY_DEPTH1,
+                "algorithmic_bytes_per_launch": rays_per_launch * b_ray,
+                "bytes_per_ray": b_ray,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -210,12 +231,27 @@ def main():
             from oracle import pyoracle as po
             import numpy as np
 
-            ob = po.Bvh.from_obj(args.scene)
-            s = po.build_sampler(po.teapot_camera(), args.width, args.height)
+            if args.scene == "atrium":
+                import ctypes as C
+
+                from minipath_amd import scenes
+
+                ob = po.Bvh.build(*scenes.atrium(1, args.detail))
+                ocam = po.Camera()
+                po.lib().mpo_camera_default(C.byref(ocam))
+                po.lib().mpo_camera_look_at(C.byref(ocam), po.vec3(-16.0, 4.2, 0.8), po.vec3(12.0, 5.5, -0.5), po.vec3(0, 1, 0))
+                ocam.f_number = 4.0
+                s = po.build_sampler(ocam, args.width, args.height)
+            else:
+                ob = po.Bvh.from_obj(args.scene)
+                s = po.build_sampler(po.teapot_camera(), args.width, args.height)
             host = img.cpu().numpy()
             bad = 0
             for t in all_tiles[:: max(1, len(all_tiles) // 6)]:
-                f, _ = ob.render_tile(s, args.width, args.height, min(args.spp, 256), args.seed, t.min_x, t.min_y, t.max_x, t.max_y)
+                if args.depth > 0:
+                    f, _, _ = ob.render_tile_paths(s, args.width, args.height, args.spp, args.seed, args.depth, t.min_x, t.min_y, t.max_x, t.max_y)
+                else:
+                    f, _ = ob.render_tile(s, args.width, args.height, args.spp, args.seed, t.min_x, t.min_y, t.max_x, t.max_y)
                 bad += int(np.sum(host[t.min_y:t.max_y, t.min_x:t.max_x].view(np.uint32) != f.view(np.uint32)))
             out["check_mismatches"] = bad
         print(json.dumps(out), flush=True)

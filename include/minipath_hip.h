@@ -77,11 +77,16 @@ typedef struct {
     uint32_t width, height;
     uint64_t seed;
     uint32_t flags;        /* MP_FLAG_* */
-    uint32_t reserved;
+    uint32_t max_depth;    /* only with MP_FLAG_PATHS: ray segments per path (>= 1); otherwise ignored (0) */
 } mp_settings;
 
 #define MP_FLAG_SHUFFLE_TILES 1u /* centre-out tile order with random noise (screen_block.rs:74-78); default: row-major */
 #define MP_FLAG_TRAVERSAL_GROUPS 2u /* camera rays on the 8-lane-group traversal instead of 64-ray packets (same results) */
+/* BUILD-DEFINED EXTENSION, no reference counterpart (the reference has no bounce loop: worker.rs:51-66 is one primary ray and
+ * |d.n|).  Diffuse grey surfaces (albedo 0.75) under a uniform white sky, paths of at most max_depth segments, cosine-weighted
+ * bounces drawn from the same per-sample Xoshiro stream (UnitDisc rejection + sqrt, Duff et al. basis), origin offset 1e-4
+ * along the normal.  rgba = (L, L, L, primary hit ? 1 : 0).  Defined operation by operation in oracle/minipath_oracle.c. */
+#define MP_FLAG_PATHS 4u
 
 /* machinery.rs:180-189 RenderProgressSnapshot */
 typedef struct { size_t finished, total; } mp_progress;
@@ -171,6 +176,11 @@ int mp_render_tile(mp_ctx *ctx, const mp_scene *scene, const mp_camera_sampler *
 int mp_render_tiles_device(mp_ctx *ctx, const mp_scene *scene, const mp_camera_sampler *sampler,
                            const mp_settings *settings, const mp_block *tiles, size_t n_tiles, float *d_rgba_f32,
                            void *stream);
+/* Same, and *d_ray_segments (device u64, overwritten) receives the number of Object::intersect calls of the launch:
+ * pixels*spp for the reference semantics, the traced path segments with MP_FLAG_PATHS. */
+int mp_render_tiles_device_counted(mp_ctx *ctx, const mp_scene *scene, const mp_camera_sampler *sampler,
+                                   const mp_settings *settings, const mp_block *tiles, size_t n_tiles, float *d_rgba_f32,
+                                   uint64_t *d_ray_segments, void *stream);
 /* machinery.rs:78-89 (tile buffer -> image copy) on the device: scatters tile-major tiles into an image-major
  * f32 frame and/or its color_to_image u8 frame (either may be NULL). */
 int mp_untile(mp_ctx *ctx, const mp_settings *settings, const mp_block *tiles, size_t n_tiles,

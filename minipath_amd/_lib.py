@@ -16,6 +16,7 @@ MP_NO_PRIM = 0xFFFFFFFF
 MP_LINK_NULL = 0xFFFFFFF8
 MP_FLAG_SHUFFLE_TILES = 1
 MP_FLAG_TRAVERSAL_GROUPS = 2
+MP_FLAG_PATHS = 4
 
 
 class MinipathError(RuntimeError):
@@ -68,7 +69,7 @@ class SettingsStruct(C.Structure):
         ("height", C.c_uint32),
         ("seed", C.c_uint64),
         ("flags", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("max_depth", C.c_uint32),
     ]
 
 
@@ -141,6 +142,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.POINTER(SamplerStruct), C.POINTER(SettingsStruct), C.POINTER(Block), C.c_size_t,
          C.c_void_p, C.c_void_p],
+    ),
+    "mp_render_tiles_device_counted": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.POINTER(SamplerStruct), C.POINTER(SettingsStruct), C.POINTER(Block), C.c_size_t,
+         C.c_void_p, C.c_void_p, C.c_void_p],
     ),
     "mp_untile": (
         C.c_int,

@@ -225,12 +225,13 @@ int finish_scene(mp_ctx* ctx, std::unique_ptr<mp_scene> s, mp_scene** out) {
 }
 
 bool valid_settings(const mp_settings* st) {
-    return st && st->tile_size > 0 && st->sample_count > 0 && st->width > 0 && st->height > 0;
+    return st && st->tile_size > 0 && st->sample_count > 0 && st->width > 0 && st->height > 0 &&
+           (!(st->flags & MP_FLAG_PATHS) || st->max_depth >= 1);
 }
 
 // Renders `tiles` into a tile-major device buffer (launch only).
 int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler& sampler, const mp_settings& st,
-                        const mp_block* d_tiles, size_t n, float* d_out, void* stream) {
+                        const mp_block* d_tiles, size_t n, float* d_out, void* stream, uint64_t* d_segments = nullptr) {
     RenderLaunch L;
     L.scene = scene->dev;
     L.sampler = sampler;
@@ -245,6 +246,8 @@ int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_samp
     L.d_counter = ctx->take_counter();
     L.cu_count = ctx->cu_count;
     L.traversal = (st.flags & MP_FLAG_TRAVERSAL_GROUPS) ? 1 : 0;
+    L.max_depth = (st.flags & MP_FLAG_PATHS) ? st.max_depth : 0u;
+    L.d_segments = reinterpret_cast<unsigned long long*>(d_segments);
     std::string err;
     int rc = launch_render_tiles(L, stream, err);
     if (rc) return fail(rc, err);
@@ -427,6 +430,12 @@ int mp_generate_rays(mp_ctx* ctx, const mp_camera_sampler* sampler, const mp_set
 int mp_render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler,
                            const mp_settings* settings, const mp_block* tiles, size_t n_tiles, float* d_rgba_f32,
                            void* stream) {
+    return mp_render_tiles_device_counted(ctx, scene, sampler, settings, tiles, n_tiles, d_rgba_f32, nullptr, stream);
+}
+
+int mp_render_tiles_device_counted(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler,
+                                   const mp_settings* settings, const mp_block* tiles, size_t n_tiles, float* d_rgba_f32,
+                                   uint64_t* d_ray_segments, void* stream) {
     if (!ctx || !scene || !sampler || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
     if (n_tiles && (!tiles || !d_rgba_f32)) return fail(MP_ERR_INVALID, "NULL tiles/output");
     if (scene->ctx != ctx) return fail(MP_ERR_INVALID, "scene belongs to another context");
@@ -444,7 +453,15 @@ int mp_render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_s
     hipError_t e = hipMemcpyAsync(d_tiles, tiles, n_tiles * sizeof(mp_block), hipMemcpyHostToDevice, st);
     int rc = MP_OK;
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(tiles)");
-    if (!rc) rc = render_tiles_device(ctx, scene, *sampler, *settings, d_tiles, n_tiles, d_rgba_f32, stream);
+    if (!rc && d_ray_segments) {
+        uint64_t init = 0;
+        if (!(settings->flags & MP_FLAG_PATHS))  // reference semantics: one Object::intersect per sample
+            for (size_t i = 0; i < n_tiles; i++)
+                init += static_cast<uint64_t>(tiles[i].max_x - tiles[i].min_x) * (tiles[i].max_y - tiles[i].min_y) * settings->sample_count;
+        e = hipMemcpyAsync(d_ray_segments, &init, sizeof init, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(ray segments)");
+    }
+    if (!rc) rc = render_tiles_device(ctx, scene, *sampler, *settings, d_tiles, n_tiles, d_rgba_f32, stream, d_ray_segments);
     (void)hipFreeAsync(d_tiles, st);
     return rc;
 }

@@ -111,10 +111,17 @@ __device__ __forceinline__ void ray_new(float ox, float oy, float oz, float dx, 
     r.iz = (r.dz == 0.0f) ? INFINITY : 1.0f / r.dz;
 }
 
-// CameraSampler::sample_ray camera.rs:176-191, seeded per (pixel, sample)
-__device__ __forceinline__ void sample_ray(const RayGen& P, uint32_t x, uint32_t y, uint32_t sample, Ray& r) {
-    Rng rng;
-    rng_seed(rng, P.seed + ((static_cast<uint64_t>(y) * P.width + x) * P.spp + sample));
+// rand_distr::UnitDisc: rejection on two Uniform(-1,1) draws (camera.rs:184)
+__device__ __forceinline__ void unit_disc(Rng& rng, float& x1, float& x2) {
+    for (;;) {
+        x1 = rng_value0_1(rng) * 2.0f + (-1.0f);
+        x2 = rng_value0_1(rng) * 2.0f + (-1.0f);
+        if (x1 * x1 + x2 * x2 <= 1.0f) break;
+    }
+}
+
+// CameraSampler::sample_ray camera.rs:176-191 on an already seeded stream
+__device__ __forceinline__ void sample_ray_rng(const RayGen& P, uint32_t x, uint32_t y, Rng& rng, Ray& r) {
     float film_u = static_cast<float>(x) + (rng_value0_1(rng) * P.jitter_scale + (-0.5f));
     float film_v = static_cast<float>(y) + (rng_value0_1(rng) * P.jitter_scale + (-0.5f));
     float fv = film_v * P.s.pixel_scale, fu = film_u * P.s.pixel_scale;
@@ -122,17 +129,24 @@ __device__ __forceinline__ void sample_ray(const RayGen& P, uint32_t x, uint32_t
     float fy = P.s.film_origin_offset[1] + P.s.up[1] * fv - P.s.right[1] * fu;
     float fz = P.s.film_origin_offset[2] + P.s.up[2] * fv - P.s.right[2] * fu;
     float x1, x2;
-    for (;;) {  // rand_distr::UnitDisc
-        x1 = rng_value0_1(rng) * 2.0f + (-1.0f);
-        x2 = rng_value0_1(rng) * 2.0f + (-1.0f);
-        if (x1 * x1 + x2 * x2 <= 1.0f) break;
-    }
+    unit_disc(rng, x1, x2);
     float a = P.s.lens_radius * x1, b = P.s.lens_radius * x2;
     float lx = P.s.right[0] * a + P.s.up[0] * b;
     float ly = P.s.right[1] * a + P.s.up[1] * b;
     float lz = P.s.right[2] * a + P.s.up[2] * b;
     ray_new(P.s.center[0] + lx, P.s.center[1] + ly, P.s.center[2] + lz, lx * P.s.lens_weight - fx,
             ly * P.s.lens_weight - fy, lz * P.s.lens_weight - fz, r);
+}
+
+__device__ __forceinline__ uint64_t sample_key(const RayGen& P, uint32_t x, uint32_t y, uint32_t sample) {
+    return P.seed + ((static_cast<uint64_t>(y) * P.width + x) * P.spp + sample);
+}
+
+// seeded per (pixel, sample): include/minipath_hip.h "Seeded mode"
+__device__ __forceinline__ void sample_ray(const RayGen& P, uint32_t x, uint32_t y, uint32_t sample, Ray& r) {
+    Rng rng;
+    rng_seed(rng, sample_key(P, x, y, sample));
+    sample_ray_rng(P, x, y, rng, r);
 }
 
 // ---- traversal --------------------------------------------------------------------------------------------------
@@ -329,6 +343,8 @@ struct RenderParams {
     float inv_spp;        // 1.0 / spp as f32 (worker.rs:44)
     uint32_t lds_per_wave;
     uint32_t debug;       // timing-only ablations (MP_DEBUG env, never set in product use): 1 = skip traversal
+    uint32_t max_depth;   // path extension only
+    unsigned long long* segments;  // path extension: ray segments traced (Object::intersect calls), may be null
 };
 
 // S = samples of one pixel in flight in a wavefront (64/S pixels x S consecutive samples per pass).
@@ -688,6 +704,132 @@ __global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P
     }
 }
 
+// ---- build-defined path extension (MP_FLAG_PATHS; the reference has no bounce loop) -----------------
+// Diffuse grey surfaces (albedo 0.75) under a uniform white sky, at most max_depth segments per path; the operations and
+// their order are those of the oracle's render_sample_paths_impl (only + - * / sqrt and compares => bit-identical).
+// Camera rays are coherent and go through the packet walk; bounce rays are incoherent: the lanes whose path is still
+// alive are compacted (ballot + mbcnt) into the wave's LDS ray queue and traced by the 8-lane-group traversal.
+constexpr float kPathAlbedo = 0.75f;
+constexpr float kPathEps = 1e-4f;
+
+template <int S>
+__global__ __launch_bounds__(256) void render_paths_kernel(RenderParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : 2;
+    constexpr int BH = 64 / S / BW;
+    const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
+    float* q = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P.lds_per_wave);
+    uint2* stack = reinterpret_cast<uint2*>(q + kQueueFloats);
+    const int pix = lane / S, sub = lane % S;
+    const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1));
+    const uint64_t lanes_lt = (1ull << lane) - 1ull;
+    const uint32_t ts = P.tile_size;
+    const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
+    const uint32_t spp = P.gen.spp;
+    unsigned long long segs = 0;  // wave-uniform
+    for (;;) {
+        uint32_t unit = 0;
+        if (lane == 0) unit = atomicAdd(P.counter, 1u);
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        if (unit >= total) break;
+        const uint32_t tile_i = unit / upt, b = unit % upt;
+        const mp_block T = P.tiles[tile_i];
+        const uint32_t px = T.min_x + (b % bx) * BW + static_cast<uint32_t>(pix % BW);
+        const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
+        const bool inpix = px < T.max_x && py < T.max_y;
+        if (__ballot(inpix) == 0) continue;
+        float acc = 0.0f, cnt = 0.0f;
+        for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+            const uint32_t s = s0 + static_cast<uint32_t>(sub);
+            const bool act = inpix && s < spp;
+            Rng rng;
+            rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+            Ray r;
+            r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+            if (act) {
+                rng_seed(rng, sample_key(P.gen, px, py, s));
+                sample_ray_rng(P.gen, px, py, rng, r);
+            }
+            float L = 0.0f, thr = 1.0f;
+            bool alive = act, primary_hit = false;
+            PacketHit h;
+            for (uint32_t depth = 1; depth <= P.max_depth; depth++) {
+                const uint64_t alive_m = __ballot(alive);
+                if (alive_m == 0) break;
+                segs += static_cast<unsigned long long>(__popcll(alive_m));
+                h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
+                const bool go = alive && may_hit_scene(P.scene, r);
+                if (depth == 1) {
+                    if (__ballot(go) != 0) {
+                        RegStack rst(nullptr, lane);
+                        HybridStack hst(reinterpret_cast<float*>(stack), lane, P.scene.stack_cap);
+                        if (P.scene.stack_cap > static_cast<uint32_t>(kPacketStackMax)) trace_packet(P.scene, r, go, hst, h);
+                        else trace_packet(P.scene, r, go, rst, h);
+                    }
+                } else {
+                    const uint64_t gm = __ballot(go);
+                    const int n = __popcll(gm), rank = __popcll(gm & lanes_lt);
+                    if (go) {
+                        q[0 * 64 + rank] = r.ox; q[1 * 64 + rank] = r.oy; q[2 * 64 + rank] = r.oz;
+                        q[3 * 64 + rank] = r.dx; q[4 * 64 + rank] = r.dy; q[5 * 64 + rank] = r.dz;
+                        q[6 * 64 + rank] = r.ix; q[7 * 64 + rank] = r.iy; q[8 * 64 + rank] = r.iz;
+                    }
+                    wave_lds_sync();
+                    trace_wave(P.scene, q, stack, n);
+                    if (go) {
+                        h.t = q[0 * 64 + rank];
+                        h.prim = as_u(q[1 * 64 + rank]);
+                        h.u = q[2 * 64 + rank];
+                        h.v = q[3 * 64 + rank];
+                    }
+                    wave_lds_sync();
+                }
+                if (alive) {
+                    if (h.prim == kNoPrim) {
+                        L = thr;  // sky radiance 1
+                        alive = false;
+                    } else {
+                        if (depth == 1) primary_hit = true;
+                        float n[3];
+                        resolve_normal(P.scene, h.prim, h.u, h.v, n);
+                        const float dn = r.dx * n[0] + r.dy * n[1] + r.dz * n[2];
+                        if (dn > 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+                        thr = thr * kPathAlbedo;
+                        if (depth == P.max_depth) {
+                            alive = false;
+                        } else {
+                            const float hx = r.ox + r.dx * h.t, hy = r.oy + r.dy * h.t, hz = r.oz + r.dz * h.t;  // geometry/mod.rs:56-58
+                            float x1, x2;
+                            unit_disc(rng, x1, x2);
+                            const float z = sqrtf(1.0f - (x1 * x1 + x2 * x2));
+                            const float sign = copysignf(1.0f, n[2]);
+                            const float a = -1.0f / (sign + n[2]);
+                            const float bb = n[0] * n[1] * a;
+                            const float t0 = 1.0f + sign * n[0] * n[0] * a, t1 = sign * bb, t2 = -sign * n[0];
+                            const float b0 = bb, b1 = sign + n[1] * n[1] * a, b2 = -n[1];
+                            ray_new(hx + n[0] * kPathEps, hy + n[1] * kPathEps, hz + n[2] * kPathEps, t0 * x1 + b0 * x2 + n[0] * z,
+                                    t1 * x1 + b1 * x2 + n[1] * z, t2 * x1 + b2 * x2 + n[2] * z, r);
+                        }
+                    }
+                }
+            }
+            cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
+            if (S == 1) {
+                acc += L;
+            } else {
+#pragma unroll
+                for (int j = 0; j < S; j++) acc += __shfl(L, (lane & ~(S - 1)) + j);
+            }
+        }
+        if (inpix && sub == 0) {
+            float m = acc * P.inv_spp;
+            size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
+            *reinterpret_cast<float4*>(P.out + off) = make_float4(m, m, m, cnt * P.inv_spp);
+        }
+    }
+    if (lane == 0 && P.segments && segs) atomicAdd(P.segments, segs);
+}
+
 // ---- batched Object::intersect over SoA ray streams (ray_bvh_intersection.rs:26-96) -------------------------
 struct TraceParams {
     DevScene scene;
@@ -835,6 +977,8 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     P.out = L.d_out;
     P.counter = L.d_counter;
     P.inv_spp = 1.0f / static_cast<float>(L.spp);
+    P.max_depth = L.max_depth;
+    P.segments = L.d_segments;
     P.lds_per_wave = lds_bytes_per_wave(L.scene.stack_cap);
     P.debug = getenv("MP_DEBUG") ? static_cast<uint32_t>(atoi(getenv("MP_DEBUG"))) : 0u;
     const uint32_t lds = P.lds_per_wave * 4;
@@ -843,6 +987,16 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     if (rc) return rc;
     const uint64_t units = static_cast<uint64_t>(L.n_tiles) * ((L.tile_size + 7) / 8) * ((L.tile_size + 7) / 8);
     const uint64_t want = (units + 3) / 4;
+    if (L.max_depth > 0) {  // build-defined path extension
+        const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / lds));
+        const int S = L.spp >= 8 ? 8 : L.spp >= 4 ? 4 : L.spp >= 2 ? 2 : 1;
+        const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want * S, static_cast<uint64_t>(L.cu_count) * per_cu));
+        if (S == 8) hipLaunchKernelGGL(render_paths_kernel<8>, dim3(grid), dim3(256), lds, st, P);
+        else if (S == 4) hipLaunchKernelGGL(render_paths_kernel<4>, dim3(grid), dim3(256), lds, st, P);
+        else if (S == 2) hipLaunchKernelGGL(render_paths_kernel<2>, dim3(grid), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL(render_paths_kernel<1>, dim3(grid), dim3(256), lds, st, P);
+        return check(hipGetLastError(), "render_paths_kernel launch", err);
+    }
     if (L.traversal == 1) {
         const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * 8));
         hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);

@@ -97,6 +97,8 @@ struct RenderLaunch {
     uint32_t* d_counter;       // work-queue head, zeroed by the launcher
     int cu_count;
     int traversal;             // 0 = ray packets (coherent camera rays), 1 = 8-lane groups
+    uint32_t max_depth;        // 0 = reference semantics (worker.rs:51-66); > 0 = build-defined path extension
+    unsigned long long* d_segments;  // optional device counter of traced ray segments (path extension)
 };
 
 int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err);

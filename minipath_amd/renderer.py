@@ -24,6 +24,7 @@ class RenderSettings:
     seed: int = 0x5EED
     shuffle_tiles: bool = False
     traversal: str = "packets"  # "packets": 64 camera rays per wave share one BVH walk; "groups": 8 lanes per ray
+    max_depth: int = 0  # 0: reference semantics (primary ray + |d.n|).  >= 1: build-defined path extension (MP_FLAG_PATHS)
 
     def as_struct(self) -> _lib.SettingsStruct:
         if self.tile_size <= 0 or self.sample_count <= 0:
@@ -34,8 +35,9 @@ class RenderSettings:
             int(self.tile_size), int(self.sample_count), int(self.resolution[0]), int(self.resolution[1]),
             int(self.seed) & 0xFFFFFFFFFFFFFFFF,
             (_lib.MP_FLAG_SHUFFLE_TILES if self.shuffle_tiles else 0)
-            | (_lib.MP_FLAG_TRAVERSAL_GROUPS if self.traversal == "groups" else 0),
-            0,
+            | (_lib.MP_FLAG_TRAVERSAL_GROUPS if self.traversal == "groups" else 0)
+            | (_lib.MP_FLAG_PATHS if self.max_depth > 0 else 0),
+            int(self.max_depth),
         )
 
 
@@ -170,7 +172,9 @@ class FrameRenderer:
         self._st = settings.as_struct()
         ts = settings.tile_size
         self.tile_buf = torch.zeros((max(len(self.tiles), 1), ts, ts, 4), dtype=torch.float32, device=self.device)
-        self.rays_per_frame = sum(t.area() for t in self.tiles) * settings.sample_count
+        self.samples_per_frame = sum(t.area() for t in self.tiles) * settings.sample_count
+        self.rays_per_frame = self.samples_per_frame  # reference semantics: one Object::intersect per sample
+        self.segments = torch.zeros(1, dtype=torch.int64, device=self.device)  # ray segments of the last launch
 
     def _stream(self):
         import torch
@@ -180,9 +184,9 @@ class FrameRenderer:
     def render(self):
         """One pass of the hot path over this renderer's tiles; asynchronous on the current stream."""
         _lib.check(
-            _lib.lib().mp_render_tiles_device(
+            _lib.lib().mp_render_tiles_device_counted(
                 self.ctx.handle, self.scene.object.handle, C.byref(self._sampler), C.byref(self._st), self._tiles_c,
-                len(self.tiles), self.tile_buf.data_ptr(), self._stream(),
+                len(self.tiles), self.tile_buf.data_ptr(), self.segments.data_ptr(), self._stream(),
             )
         )
         return self.tile_buf

@@ -1149,6 +1149,64 @@ static void render_sample_impl(const mpo_bvh *b, const mpo_sampler *s, uint32_t 
     }
 }
 
+/* ---- build-defined path extension (NO reference counterpart: the reference has no bounce loop) --------
+ * Diffuse grey surfaces (albedo 0.75) under a uniform white sky, paths of at most max_depth segments:
+ *   L = 0, throughput = 1; for depth = 1..max_depth: trace; miss -> L = throughput (sky radiance 1), stop;
+ *   hit -> n = shading normal turned against the ray; throughput *= 0.75; at depth == max_depth stop (L stays 0);
+ *   next direction = cosine-weighted about n: (x, y) = UnitDisc rejection sample from the SAME Xoshiro stream,
+ *   z = sqrt(1 - (x*x + y*y)); orthonormal basis of Duff et al. 2017 (branchless, copysign); origin = point + n * 1e-4.
+ * Only + - * / sqrt and comparisons, so the GPU reproduces it bit for bit.  rgba = (L, L, L, primary hit ? 1 : 0). */
+static _Thread_local uint32_t g_max_depth = 0;      /* 0 = reference semantics (worker.rs:51-66) */
+static _Thread_local uint64_t g_segments = 0;
+
+#define MPO_PATH_ALBEDO 0.75f
+#define MPO_PATH_EPS 1e-4f
+
+static void render_sample_paths_impl(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t spp, uint64_t seed,
+                                     uint32_t x, uint32_t y, uint32_t sample, uint32_t max_depth, stack_cache *st, float rgba[4],
+                                     mpo_counters *cnt, uint64_t *segments) {
+    mpo_rng rng;
+    mpo_rng_seed(&rng, mpo_sample_key(seed, width, spp, x, y, sample));
+    mpo_ray ray;
+    mpo_sample_ray(s, x, y, &rng, &ray);
+    float L = 0.0f, thr = 1.0f, alpha = 0.0f;
+    for (uint32_t depth = 1; depth <= max_depth; depth++) {
+        mpo_hit h;
+        bvh_intersect_impl(b, &ray, st, &h, cnt);
+        if (segments) (*segments)++;
+        if (!h.hit) { L = thr; break; }
+        if (depth == 1) alpha = 1.0f;
+        float n[3] = {h.normal[0], h.normal[1], h.normal[2]};
+        float dn = ray.d[0] * n[0] + ray.d[1] * n[1] + ray.d[2] * n[2];
+        if (dn > 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+        thr = thr * MPO_PATH_ALBEDO;
+        if (depth == max_depth) break;
+        float d2[2];
+        mpo_rng_unit_disc(&rng, d2);
+        float z = sqrtf(1.0f - (d2[0] * d2[0] + d2[1] * d2[1]));
+        float sign = copysignf(1.0f, n[2]);
+        float a = -1.0f / (sign + n[2]);
+        float bb = n[0] * n[1] * a;
+        float t[3] = {1.0f + sign * n[0] * n[0] * a, sign * bb, -sign * n[0]};
+        float bt[3] = {bb, sign + n[1] * n[1] * a, -n[1]};
+        float dir[3], org[3];
+        for (int k = 0; k < 3; k++) {
+            dir[k] = t[k] * d2[0] + bt[k] * d2[1] + n[k] * z;
+            org[k] = h.point[k] + n[k] * MPO_PATH_EPS;
+        }
+        mpo_ray_new(org, dir, &ray);
+    }
+    rgba[0] = rgba[1] = rgba[2] = L;
+    rgba[3] = alpha;
+}
+
+void mpo_render_sample_paths(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t spp, uint64_t seed, uint32_t x,
+                             uint32_t y, uint32_t sample, uint32_t max_depth, float rgba[4], uint64_t *segments) {
+    stack_cache st = {0};
+    render_sample_paths_impl(b, s, width, spp, seed, x, y, sample, max_depth, &st, rgba, NULL, segments);
+    free(st.e);
+}
+
 void mpo_render_sample(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t spp, uint64_t seed,
                        uint32_t x, uint32_t y, uint32_t sample, float rgba[4], mpo_counters *cnt) {
     stack_cache st = {0};
@@ -1157,6 +1215,16 @@ void mpo_render_sample(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, u
 }
 
 /* worker.rs:69-76 : (c*255).round() half away from zero, clamp, `as u8` (NaN -> 0) */
+void mpo_render_tile_paths(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t height, uint32_t spp,
+                           uint64_t seed, uint32_t max_depth, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                           float *rgba_f32, uint8_t *rgba_u8, uint64_t *segments) {
+    g_max_depth = max_depth;
+    g_segments = 0;
+    mpo_render_tile(b, s, width, height, spp, seed, x0, y0, x1, y1, rgba_f32, rgba_u8, NULL);
+    if (segments) *segments = g_segments;
+    g_max_depth = 0;
+}
+
 void mpo_color_to_image(const float rgba[4], uint8_t out[4]) {
     for (int k = 0; k < 4; k++) {
         float x = roundf(rgba[k] * 255.0f);
@@ -1175,7 +1243,8 @@ static void render_tile_impl(const mpo_bvh *b, const mpo_sampler *s, uint32_t wi
             float sum[4] = {0, 0, 0, 0};
             for (uint32_t i = 0; i < spp; i++) { /* :41-43 */
                 float c[4];
-                render_sample_impl(b, s, width, spp, seed, x, y, i, st, c, cnt);
+                if (g_max_depth == 0) { render_sample_impl(b, s, width, spp, seed, x, y, i, st, c, cnt); g_segments++; }
+                else render_sample_paths_impl(b, s, width, spp, seed, x, y, i, g_max_depth, st, c, cnt, &g_segments);
                 for (int k = 0; k < 4; k++) sum[k] += c[k];
             }
             float px[4];
@@ -1206,6 +1275,7 @@ typedef struct {
     float *f32; uint8_t *u8;
     pthread_mutex_t mu; mpo_counters total; int want_cnt;
     atomic_ullong rays;
+    uint32_t max_depth; atomic_ullong segments;
 } mt_state;
 
 static void *mt_worker(void *arg) {
@@ -1213,6 +1283,8 @@ static void *mt_worker(void *arg) {
     stack_cache st = {0};
     mpo_counters cnt = {0};
     unsigned long long rays = 0;
+    g_max_depth = S->max_depth;
+    g_segments = 0;
     for (;;) {
         size_t id = atomic_fetch_add_explicit(&S->next, 1, memory_order_acq_rel); /* get_next_tile :205-208 */
         size_t ti = id * S->stride;
@@ -1227,6 +1299,8 @@ static void *mt_worker(void *arg) {
     }
     free(st.e);
     atomic_fetch_add(&S->rays, rays);
+    atomic_fetch_add(&S->segments, g_segments);
+    g_max_depth = 0;
     if (S->want_cnt) {
         pthread_mutex_lock(&S->mu);
         S->total.rays += cnt.rays; S->total.inner_visited += cnt.inner_visited;
@@ -1237,11 +1311,14 @@ static void *mt_worker(void *arg) {
     return NULL;
 }
 
-double mpo_render_image_mt(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t height, uint32_t spp,
-                           uint64_t seed, uint32_t tile, int nthreads, size_t max_tiles, size_t tile_stride,
-                           float *rgba_f32, uint8_t *rgba_u8, uint64_t *rays_out, mpo_counters *cnt) {
+static double render_image_mt_impl(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t height, uint32_t spp,
+                                   uint64_t seed, uint32_t tile, int nthreads, size_t max_tiles, size_t tile_stride,
+                                   float *rgba_f32, uint8_t *rgba_u8, uint64_t *rays_out, mpo_counters *cnt, uint32_t max_depth,
+                                   uint64_t *segments_out) {
     mt_state S;
     memset(&S, 0, sizeof(S));
+    S.max_depth = max_depth;
+    atomic_init(&S.segments, 0);
     S.b = b; S.s = s; S.width = width; S.height = height; S.spp = spp; S.tile = tile; S.seed = seed;
     S.ntiles = mpo_tile_ordering(0, 0, width, height, tile, 0, NULL, 0);
     S.tiles = malloc(S.ntiles * 16 + 16);
@@ -1263,6 +1340,22 @@ double mpo_render_image_mt(const mpo_bvh *b, const mpo_sampler *s, uint32_t widt
     free(th); free(S.tiles);
     pthread_mutex_destroy(&S.mu);
     if (rays_out) *rays_out = atomic_load(&S.rays);
+    if (segments_out) *segments_out = atomic_load(&S.segments);
     if (cnt) *cnt = S.total;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+double mpo_render_image_mt(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t height, uint32_t spp,
+                           uint64_t seed, uint32_t tile, int nthreads, size_t max_tiles, size_t tile_stride,
+                           float *rgba_f32, uint8_t *rgba_u8, uint64_t *rays_out, mpo_counters *cnt) {
+    return render_image_mt_impl(b, s, width, height, spp, seed, tile, nthreads, max_tiles, tile_stride, rgba_f32, rgba_u8, rays_out,
+                                cnt, 0, NULL);
+}
+
+/* path extension: *segments_out = Object::intersect calls (ray segments) */
+double mpo_render_image_paths_mt(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t height, uint32_t spp,
+                                 uint64_t seed, uint32_t max_depth, uint32_t tile, int nthreads, size_t max_tiles,
+                                 size_t tile_stride, float *rgba_f32, uint8_t *rgba_u8, uint64_t *segments_out) {
+    return render_image_mt_impl(b, s, width, height, spp, seed, tile, nthreads, max_tiles, tile_stride, rgba_f32, rgba_u8, NULL, NULL,
+                                max_depth, segments_out);
 }

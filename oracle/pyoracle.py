@@ -172,6 +172,15 @@ def lib() -> C.CDLL:
         C.c_size_t, C.c_size_t, f32p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(Counters),
     ]
     L.mpo_render_image_mt.restype = C.c_double
+    L.mpo_render_tile_paths.argtypes = [
+        C.c_void_p, C.POINTER(Sampler), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
+        C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64),
+    ]
+    L.mpo_render_image_paths_mt.argtypes = [
+        C.c_void_p, C.POINTER(Sampler), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int,
+        C.c_size_t, C.c_size_t, f32p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64),
+    ]
+    L.mpo_render_image_paths_mt.restype = C.c_double
     _lib = L
     return L
 
@@ -360,6 +369,29 @@ class Bvh:
             u8.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(counters) if counters is not None else None,
         )
         return f, u8
+
+    def render_tile_paths(self, sampler: Sampler, width, height, spp, seed, max_depth, x0, y0, x1, y1):
+        """Build-defined path extension.  Returns f32 [h,w,4], u8, ray segments traced."""
+        tw, th = x1 - x0, y1 - y0
+        f = np.zeros((th, tw, 4), np.float32)
+        u8 = np.zeros((th, tw, 4), np.uint8)
+        seg = C.c_uint64(0)
+        lib().mpo_render_tile_paths(
+            self.h, C.byref(sampler), width, height, spp, C.c_uint64(seed), max_depth, x0, y0, x1, y1, _f32p(f),
+            u8.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(seg),
+        )
+        return f, u8, seg.value
+
+    def render_image_paths_mt(self, sampler: Sampler, width, height, spp, seed, max_depth, tile=64, nthreads=1, max_tiles=0,
+                              tile_stride=1):
+        f = np.zeros((height, width, 4), np.float32)
+        u8 = np.zeros((height, width, 4), np.uint8)
+        seg = C.c_uint64(0)
+        secs = lib().mpo_render_image_paths_mt(
+            self.h, C.byref(sampler), width, height, spp, C.c_uint64(seed), max_depth, tile, nthreads, max_tiles, tile_stride,
+            _f32p(f), u8.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(seg),
+        )
+        return f, u8, secs, seg.value
 
     def render_image_mt(self, sampler: Sampler, width, height, spp, seed, tile=64, nthreads=1, max_tiles=0,
                         tile_stride=1, want_counters=False):

@@ -403,3 +403,65 @@ def test_atrium_deep_tree(ctx, oracle, traversal):
     o, d = meshes.random_rays(20000, 5, bmin, bmax)
     got, exp = _trace_both(scene, orc, o, d)
     _assert_hits_equal(got, exp)
+
+
+@pytest.mark.parametrize("max_depth,spp,res,tile", [(8, 16, (256, 256), (64, 96, 128, 160)), (1, 5, (256, 256), (96, 96, 160, 160)),
+                                                    (3, 9, (250, 130), (192, 64, 250, 128)), (2, 1, (256, 256), (64, 64, 128, 128))])
+def test_path_extension_tile_bit_exact(teapot, oracle, teapot_oracle_bvh, max_depth, spp, res, tile):
+    """Build-defined path extension (MP_FLAG_PATHS; no reference counterpart): GPU == oracle restatement bit for bit,
+    including the number of traced ray segments.  Camera rays on the packet walk, bounce rays compacted into the LDS
+    queue and traced by the 8-lane-group traversal."""
+    import torch
+
+    cam = mp.Camera.teapot_view()
+    st = mp.RenderSettings(64, spp, res, seed=SEED, max_depth=max_depth)
+    fr = mp.FrameRenderer(teapot, cam, st, tiles=[mp.ScreenBlock(*tile)])
+    buf = fr.render()
+    torch.cuda.synchronize()
+    tw, th = tile[2] - tile[0], tile[3] - tile[1]
+    got = buf[0, :th, :tw].cpu().numpy()
+    of, ou8, seg = teapot_oracle_bvh.render_tile_paths(oracle.build_sampler(oracle.teapot_camera(), *res), res[0], res[1], spp, SEED, max_depth, *tile)
+    assert np.array_equal(bits(got), bits(of)), f"{int(np.sum(bits(got) != bits(of)))} differ"
+    assert int(fr.segments.item()) == seg
+    assert seg >= tw * th * spp
+    if max_depth > 1:
+        assert seg > tw * th * spp  # some paths bounced
+
+
+def test_path_extension_atrium_and_frame(ctx, oracle):
+    """Interior scene (every path bounces until max_depth or escapes never): deep tree + LDS queue/stack pressure."""
+    import ctypes as C
+
+    import torch
+
+    from minipath_amd import scenes
+
+    pos, nrm, tex, tri = scenes.atrium(1, 0.05)
+    scene = mp.Scene(mp.TriangleBvh.build(pos, nrm, tex, tri, ctx))
+    orc = oracle.Bvh.build(pos, nrm, tex, tri)
+    oc = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(oc))
+    oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(-16.0, 4.2, 0.8), oracle.vec3(12.0, 5.5, -0.5), oracle.vec3(0, 1, 0))
+    oc.f_number = 4.0
+    res = (96, 64)
+    st = mp.RenderSettings(32, 6, res, seed=5, max_depth=4)
+    fr = mp.FrameRenderer(scene, scenes.atrium_camera(), st)
+    fr.render()
+    img, _ = fr.untile()
+    torch.cuda.synchronize()
+    of, ou8, secs, seg = orc.render_image_paths_mt(oracle.build_sampler(oc, *res), res[0], res[1], 6, 5, 4, 32, 8)
+    assert np.array_equal(bits(img.cpu().numpy()), bits(of))
+    assert int(fr.segments.item()) == seg
+    assert seg > 3 * res[0] * res[1] * 6  # closed hall: almost every path uses all four segments
+
+
+def test_reference_mode_segment_count(teapot):
+    import torch
+
+    st = mp.RenderSettings(64, 3, (256, 256), seed=SEED)
+    fr = mp.FrameRenderer(teapot, mp.Camera.teapot_view(), st)
+    fr.render()
+    torch.cuda.synchronize()
+    assert int(fr.segments.item()) == 256 * 256 * 3 == fr.rays_per_frame
+    with pytest.raises(ValueError):
+        mp.RenderSettings(64, 1, (8, 8), traversal="nope").as_struct()
