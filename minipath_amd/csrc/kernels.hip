@@ -342,7 +342,6 @@ struct RenderParams {
     uint32_t* counter;    // work-queue head
     float inv_spp;        // 1.0 / spp as f32 (worker.rs:44)
     uint32_t lds_per_wave;
-    uint32_t debug;       // timing-only ablations (MP_DEBUG env, never set in product use): 1 = skip traversal
     uint32_t max_depth;   // path extension only
     unsigned long long* segments;  // path extension: ray segments traced (Object::intersect calls), may be null
 };
@@ -391,9 +390,9 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
                 q[6 * 64 + rank] = r.ix; q[7 * 64 + rank] = r.iy; q[8 * 64 + rank] = r.iz;
             }
             wave_lds_sync();
-            if (!(P.debug & 1u)) trace_wave(P.scene, q, stack, n);
+            trace_wave(P.scene, q, stack, n);
             float c = 0.0f, h = 0.0f;
-            if (queued && !(P.debug & 1u)) {
+            if (queued) {
                 uint32_t prim = as_u(q[1 * 64 + rank]);
                 if (prim != kNoPrim) {
                     float nn[3];
@@ -980,7 +979,6 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     P.max_depth = L.max_depth;
     P.segments = L.d_segments;
     P.lds_per_wave = lds_bytes_per_wave(L.scene.stack_cap);
-    P.debug = getenv("MP_DEBUG") ? static_cast<uint32_t>(atoi(getenv("MP_DEBUG"))) : 0u;
     const uint32_t lds = P.lds_per_wave * 4;
     if (lds > 160 * 1024) { err = "scene too deep for the LDS traversal stacks"; return MP_ERR_UNSUPPORTED; }
     int rc = check(hipMemsetAsync(L.d_counter, 0, sizeof(uint32_t), st), "hipMemsetAsync(counter)", err);
@@ -1005,7 +1003,6 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     // samples of one pixel in flight per pass: 8 keeps the 64 rays of a pass within a 4x2 pixel footprint and makes
     // the work units 8x smaller than a whole 8x8 block (measured best on MI355X: profiles/r01_notes.md)
     int S = L.spp >= 8 ? 8 : L.spp >= 4 ? 4 : L.spp >= 2 ? 2 : 1;
-    if (getenv("MP_S")) S = atoi(getenv("MP_S"));  // experiments only
     const bool lds_stack = L.scene.stack_cap > static_cast<uint32_t>(kPacketStackMax);
     P.lds_per_wave = lds_stack ? ((L.scene.stack_cap - 64u) * 20u + 15u) & ~15u : 0u;
     const uint32_t plds = P.lds_per_wave * 4;
