@@ -98,7 +98,8 @@ typedef struct {
     uint32_t packet_count;   /* RelativeTriangle8, 144 B each */
     uint32_t vertex_count;
     uint32_t triangle_count; /* real (unpadded) triangles */
-    uint32_t depth;          /* max inner nodes on a root-to-leaf path; traversal stack <= 7*depth+1 */
+    uint32_t depth;          /* max inner nodes on a root-to-leaf path */
+    uint32_t stack_bound;    /* exact upper bound of the traversal stack for any ray (<= 7*depth+1) */
     float bbox_min[3], bbox_max[3];
     uint64_t device_bytes;
 } mp_scene_info;
@@ -123,6 +124,9 @@ const char *mp_version(void);
 int mp_ctx_create(int device_id, mp_ctx **out);
 void mp_ctx_destroy(mp_ctx *ctx);
 int mp_ctx_device(const mp_ctx *ctx, int *device_id, int *cu_count);
+/* Tuning knobs.  "packet_stack_registers" (1..64, default 64): entries of the ray-packet walk's shared stack kept in registers; the
+ * rest of the scene's stack bound lives in LDS.  Results never depend on it (tests lower it to cover the LDS path). */
+int mp_ctx_set_option(mp_ctx *ctx, const char *key, int value);
 
 /* ---- camera.rs ------------------------------------------------------------------------------------------ */
 int mp_camera_default(mp_camera *cam);                                                            /* :42-52 */

@@ -85,6 +85,7 @@ class SceneInfo(C.Structure):
         ("vertex_count", C.c_uint32),
         ("triangle_count", C.c_uint32),
         ("depth", C.c_uint32),
+        ("stack_bound", C.c_uint32),
         ("bbox_min", C.c_float * 3),
         ("bbox_max", C.c_float * 3),
         ("device_bytes", C.c_uint64),
@@ -113,6 +114,7 @@ SIGNATURES = {
     "mp_version": (C.c_char_p, []),
     "mp_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "mp_ctx_destroy": (None, [C.c_void_p]),
+    "mp_ctx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "mp_ctx_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "mp_camera_default": (C.c_int, [C.POINTER(CameraStruct)]),
     "mp_camera_look_at": (C.c_int, [C.POINTER(CameraStruct), _f3, _f3, _f3]),

@@ -56,6 +56,7 @@ struct mp_ctx {
     static constexpr uint32_t kCounters = 256;
     uint32_t* d_counters = nullptr;
     std::atomic<uint32_t> next_counter{0};
+    std::atomic<uint32_t> packet_stack_regs{64};
     uint32_t* take_counter() { return d_counters + (next_counter.fetch_add(1, std::memory_order_relaxed) % kCounters); }
 };
 
@@ -188,7 +189,25 @@ int upload_scene(mp_scene* s) {
     s->dev.root = h.root;
     s->dev.inner_count = static_cast<uint32_t>(ni);
     s->dev.packet_count = static_cast<uint32_t>(np);
-    s->dev.stack_cap = 7 * h.depth + 1;
+    // Exact bound of the traversal stack: a node pushes at most its real (non-null) children in ascending order and pops
+    // them in descending order, so while the subtree of the child at position p is walked, p lower siblings wait below it.
+    // bound(node) = max(#children, max_p(p + bound(child_p))); far below the 7*depth+1 of eight-way nodes for the
+    // reference's narrow trees (teapot 22 vs 36, atrium 54 vs 197), which keeps the packet walk's stack in registers.
+    {
+        std::vector<uint32_t> bound(ni, 0);
+        for (size_t n = ni; n-- > 0;) {  // children have larger indices than their parent (pre-order numbering)
+            uint32_t p = 0, best = 0;
+            for (int i = 0; i < 8; i++) {
+                const uint32_t l = h.inner[n].link[i];
+                if (l == MP_LINK_NULL) continue;
+                const uint32_t sub = (l & 7u) == 0u ? bound[l >> 3] : 0u;
+                best = std::max(best, p + sub);
+                p++;
+            }
+            bound[n] = std::max(best, p);
+        }
+        s->dev.stack_cap = std::max<uint32_t>(1u, ((h.root & 7u) == 0u && h.root != MP_LINK_NULL) ? bound[h.root >> 3] : 1u);
+    }
     s->dev.has_pre = 0;
     if ((h.root & 7u) == 0u && h.root != MP_LINK_NULL) {  // root is an inner node
         const float* o = &nodes[static_cast<size_t>(h.root >> 3) * kNodeDwords];
@@ -234,6 +253,7 @@ int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_samp
                         const mp_block* d_tiles, size_t n, float* d_out, void* stream, uint64_t* d_segments = nullptr) {
     RenderLaunch L;
     L.scene = scene->dev;
+    L.scene.packet_stack_regs = ctx->packet_stack_regs.load();
     L.sampler = sampler;
     L.width = st.width;
     L.height = st.height;
@@ -284,6 +304,16 @@ void mp_ctx_destroy(mp_ctx* ctx) {
     DeviceGuard g(ctx->device);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     delete ctx;
+}
+
+int mp_ctx_set_option(mp_ctx* ctx, const char* key, int value) {
+    if (!ctx || !key) return fail(MP_ERR_INVALID, "NULL argument");
+    if (std::strcmp(key, "packet_stack_registers") == 0) {
+        if (value < 1 || value > 64) return fail(MP_ERR_INVALID, "packet_stack_registers must be in 1..64");
+        ctx->packet_stack_regs.store(static_cast<uint32_t>(value));
+        return MP_OK;
+    }
+    return fail(MP_ERR_INVALID, std::string("unknown option: ") + key);
 }
 
 int mp_ctx_device(const mp_ctx* ctx, int* device_id, int* cu_count) {
@@ -378,6 +408,7 @@ int mp_scene_info_get(const mp_scene* s, mp_scene_info* out) {
     out->vertex_count = s->host.vertex_count;
     out->triangle_count = s->host.triangle_count;
     out->depth = s->host.depth;
+    out->stack_bound = s->ctx ? s->dev.stack_cap : 0;
     for (int k = 0; k < 3; k++) {
         out->bbox_min[k] = s->host.bbox.mn[k];
         out->bbox_max[k] = s->host.bbox.mx[k];

@@ -469,7 +469,6 @@ struct PacketHit {
 // whose best.t shrank after the push, so while no lane accepted a hit since then (entry not "stale") the pushed
 // mask is the answer; otherwise t1 is recomputed from the child's box (same operations, same bits as at push time).
 constexpr uint32_t kSrcRoot = 0xFFFFFFFFu;
-constexpr int kPacketStackMax = 64;
 
 template <bool PATCH_NAN>
 __device__ __forceinline__ float slab_entry(float bnx, float bny, float bnz, float bxx, float bxy, float bxz, const Ray& r) {
@@ -511,24 +510,25 @@ struct HybridStack {
     uint4* ent;
     uint32_t* ep;
     uint32_t epoch;
-    __device__ __forceinline__ HybridStack(float* lds, int lane_, uint32_t cap)
-        : reg(nullptr, lane_), ent(reinterpret_cast<uint4*>(lds)), ep(nullptr), epoch(0) {
-        ep = reinterpret_cast<uint32_t*>(ent + (cap > 64u ? cap - 64u : 0u));
+    int nreg;  // entries kept in registers (<= 64; lowered only by the mp_ctx_set_option test knob)
+    __device__ __forceinline__ HybridStack(float* lds, int lane_, uint32_t cap, uint32_t nreg_)
+        : reg(nullptr, lane_), ent(reinterpret_cast<uint4*>(lds)), ep(nullptr), epoch(0), nreg(static_cast<int>(nreg_)) {
+        ep = reinterpret_cast<uint32_t*>(ent + (cap > nreg_ ? cap - nreg_ : 0u));
     }
     __device__ __forceinline__ void push(int sp, uint32_t l, uint32_t s, uint64_t m) {
-        if (sp < kPacketStackMax) {
+        if (sp < nreg) {
             reg.push(sp, l, s, m);
         } else if (reg.lane == 0) {
-            ent[sp - kPacketStackMax] = make_uint4(l, s, static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32));
-            ep[sp - kPacketStackMax] = epoch;
+            ent[sp - nreg] = make_uint4(l, s, static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32));
+            ep[sp - nreg] = epoch;
         }
     }
     __device__ __forceinline__ void pop(int sp, uint32_t& l, uint32_t& s, uint64_t& m, bool& is_stale) const {
-        if (sp < kPacketStackMax) {
+        if (sp < nreg) {
             reg.pop(sp, l, s, m, is_stale);
         } else {
-            const uint4 e = ent[sp - kPacketStackMax];
-            const uint32_t pe = ep[sp - kPacketStackMax];
+            const uint4 e = ent[sp - nreg];
+            const uint32_t pe = ep[sp - nreg];
             l = __builtin_amdgcn_readfirstlane(e.x);
             s = __builtin_amdgcn_readfirstlane(e.y);
             m = __builtin_amdgcn_readfirstlane(e.z) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(e.w)) << 32);
@@ -536,7 +536,7 @@ struct HybridStack {
         }
     }
     __device__ __forceinline__ void all_stale() { reg.all_stale(); epoch++; }
-    __device__ __forceinline__ void sync(int sp) { if (sp > kPacketStackMax) wave_lds_sync(); }
+    __device__ __forceinline__ void sync(int sp) { if (sp > nreg) wave_lds_sync(); }
 };
 
 // MODE 1: every active ray has finite inverse directions (no 0*inf, so the NaN patches of aabb.rs:262-267 are dead code).
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P
             if (__ballot(go) != 0) {
                 float* lds = reinterpret_cast<float*>(smem + static_cast<size_t>(static_cast<int>(threadIdx.x) >> 6) * P.lds_per_wave);
                 if (LDS_STACK) {
-                    HybridStack st(lds, lane, P.scene.stack_cap);
+                    HybridStack st(lds, lane, P.scene.stack_cap, P.scene.packet_stack_regs);
                     trace_packet(P.scene, r, go, st, h);
                 } else {
                     RegStack st(lds, lane);
@@ -761,8 +761,8 @@ __global__ __launch_bounds__(256) void render_paths_kernel(RenderParams P) {
                 if (depth == 1) {
                     if (__ballot(go) != 0) {
                         RegStack rst(nullptr, lane);
-                        HybridStack hst(reinterpret_cast<float*>(stack), lane, P.scene.stack_cap);
-                        if (P.scene.stack_cap > static_cast<uint32_t>(kPacketStackMax)) trace_packet(P.scene, r, go, hst, h);
+                        HybridStack hst(reinterpret_cast<float*>(stack), lane, P.scene.stack_cap, P.scene.packet_stack_regs);
+                        if (P.scene.stack_cap > P.scene.packet_stack_regs) trace_packet(P.scene, r, go, hst, h);
                         else trace_packet(P.scene, r, go, rst, h);
                     }
                 } else {
@@ -1003,8 +1003,8 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     // samples of one pixel in flight per pass: 8 keeps the 64 rays of a pass within a 4x2 pixel footprint and makes
     // the work units 8x smaller than a whole 8x8 block (measured best on MI355X: profiles/r01_notes.md)
     int S = L.spp >= 8 ? 8 : L.spp >= 4 ? 4 : L.spp >= 2 ? 2 : 1;
-    const bool lds_stack = L.scene.stack_cap > static_cast<uint32_t>(kPacketStackMax);
-    P.lds_per_wave = lds_stack ? ((L.scene.stack_cap - 64u) * 20u + 15u) & ~15u : 0u;
+    const bool lds_stack = L.scene.stack_cap > L.scene.packet_stack_regs;
+    P.lds_per_wave = lds_stack ? ((L.scene.stack_cap - L.scene.packet_stack_regs) * 20u + 15u) & ~15u : 0u;
     const uint32_t plds = P.lds_per_wave * 4;
     if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
     const uint32_t per_cu = plds ? std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds)) : 8u;

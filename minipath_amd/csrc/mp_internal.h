@@ -76,7 +76,8 @@ struct DevScene {
     uint32_t root = MP_LINK_NULL;
     uint32_t inner_count = 0;
     uint32_t packet_count = 0;
-    uint32_t stack_cap = 1;          // 7*depth+1
+    uint32_t stack_cap = 1;          // exact traversal-stack bound (upload_scene)
+    uint32_t packet_stack_regs = 64; // entries of the packet walk's stack held in registers (test knob, <= 64)
     // union of the root inner node's (non-null) decompressed child boxes: exact conservative ray pre-test
     uint32_t has_pre = 0;
     float pre_min[3] = {0, 0, 0}, pre_max[3] = {0, 0, 0};

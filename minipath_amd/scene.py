@@ -24,6 +24,10 @@ class Context:
         _lib.check(_lib.lib().mp_ctx_device(self.handle, None, C.byref(cu)))
         return cu.value
 
+    def set_option(self, key: str, value: int) -> None:
+        """mp_ctx_set_option: tuning knobs (results never depend on them)."""
+        _lib.check(_lib.lib().mp_ctx_set_option(self.handle, key.encode(), int(value)))
+
     def close(self):
         if getattr(self, "handle", None):
             _lib.lib().mp_ctx_destroy(self.handle)

@@ -371,17 +371,42 @@ def test_render_synthetic_scenes(ctx, oracle, name, traversal):
     assert (of[..., 3] > 0).mean() > 0.05
 
 
+@pytest.mark.parametrize("regs", [64, 3])
+def test_packet_stack_in_lds(oracle, teapot_oracle_bvh, regs):
+    """The packet walk keeps the first `packet_stack_registers` entries of its shared stack in registers and the rest in
+    LDS (HybridStack).  With the exact stack bound the shipped scenes fit in registers, so the knob is lowered to 3 to
+    drive the LDS path (incl. the epoch-based lazy cull) on the teapot: the image must not change."""
+    c = mp.Context(0)
+    c.set_option("packet_stack_registers", regs)
+    scene = mp.Scene(mp.TriangleBvh.with_obj(TEAPOT, c))
+    assert scene.object.info().stack_bound > 3
+    for max_depth in (0, 3):
+        st = mp.RenderSettings(64, 8, (256, 256), seed=SEED, max_depth=max_depth)
+        fr = mp.FrameRenderer(scene, mp.Camera.teapot_view(), st, tiles=[mp.ScreenBlock(64, 96, 128, 160)])
+        got = fr.render()[0].cpu().numpy()
+        s = oracle.build_sampler(oracle.teapot_camera(), 256, 256)
+        if max_depth:
+            of, _, _ = teapot_oracle_bvh.render_tile_paths(s, 256, 256, 8, SEED, max_depth, 64, 96, 128, 160)
+        else:
+            of, _ = teapot_oracle_bvh.render_tile(s, 256, 256, 8, SEED, 64, 96, 128, 160)
+        assert np.array_equal(bits(got), bits(of))
+    with pytest.raises(mp.MinipathError):
+        c.set_option("packet_stack_registers", 65)
+    with pytest.raises(mp.MinipathError):
+        c.set_option("nope", 1)
+
+
 @pytest.mark.parametrize("traversal", ["packets", "groups"])
 def test_atrium_deep_tree(ctx, oracle, traversal):
-    """Sponza stand-in (minipath_amd.scenes.atrium) at 5 % detail: 13 k triangles, 10 inner levels => traversal stack
-    bound 71 > 64, i.e. the LDS variant of the packet stack; camera inside the hall (every ray hits something)."""
+    """Sponza stand-in (minipath_amd.scenes.atrium) at 5 % detail: 13 k triangles, 10 inner levels (7*depth+1 = 71, exact
+    stack bound far lower); camera inside the hall (every ray hits something)."""
     import ctypes as C
 
     from minipath_amd import scenes
 
     pos, nrm, tex, tri = scenes.atrium(1, 0.05)
     bvh = mp.TriangleBvh.build(pos, nrm, tex, tri, ctx)
-    assert 7 * bvh.info().depth + 1 > 64
+    assert 7 * bvh.info().depth + 1 > 64 and 1 < bvh.info().stack_bound <= 7 * bvh.info().depth + 1
     scene = mp.Scene(bvh)
     orc = oracle.Bvh.build(pos, nrm, tex, tri)
     cam = scenes.atrium_camera()
