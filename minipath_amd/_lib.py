@@ -181,6 +181,12 @@ def lib() -> C.CDLL:
                 f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C minipath_amd/csrc` -- minipath_amd has no CPU fallback"
             )
+        try:
+            # torch ships its own libamdhip64; the process must hold ONE HIP runtime, so let torch's load first when it
+            # is installed (otherwise a later torch.cuda initialisation finds "No HIP GPUs")
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

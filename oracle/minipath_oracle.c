@@ -1359,3 +1359,10 @@ double mpo_render_image_paths_mt(const mpo_bvh *b, const mpo_sampler *s, uint32_
     return render_image_mt_impl(b, s, width, height, spp, seed, tile, nthreads, max_tiles, tile_stride, rgba_f32, rgba_u8, NULL, NULL,
                                 max_depth, segments_out);
 }
+
+/* same with traversal counters (diagnostics) */
+double mpo_render_image_paths_mt_cnt(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t height, uint32_t spp,
+                                     uint64_t seed, uint32_t max_depth, uint32_t tile, int nthreads, float *rgba_f32,
+                                     uint64_t *segments_out, mpo_counters *cnt) {
+    return render_image_mt_impl(b, s, width, height, spp, seed, tile, nthreads, 0, 1, rgba_f32, NULL, NULL, cnt, max_depth, segments_out);
+}
