@@ -489,8 +489,9 @@ int mp_render_tiles_device_counted(mp_ctx* ctx, const mp_scene* scene, const mp_
         if (!(settings->flags & MP_FLAG_PATHS))  // reference semantics: one Object::intersect per sample
             for (size_t i = 0; i < n_tiles; i++)
                 init += static_cast<uint64_t>(tiles[i].max_x - tiles[i].min_x) * (tiles[i].max_y - tiles[i].min_y) * settings->sample_count;
-        e = hipMemcpyAsync(d_ray_segments, &init, sizeof init, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(ray segments)");
+        std::string err;  // the value travels as a kernel argument: no host memory is read after this call returns
+        rc = launch_set_u64(reinterpret_cast<unsigned long long*>(d_ray_segments), init, stream, err);
+        if (rc) fail(rc, err);
     }
     if (!rc) rc = render_tiles_device(ctx, scene, *sampler, *settings, d_tiles, n_tiles, d_rgba_f32, stream, d_ray_segments);
     (void)hipFreeAsync(d_tiles, st);

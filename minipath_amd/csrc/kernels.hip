@@ -933,6 +933,8 @@ __global__ __launch_bounds__(256) void untile_kernel(uint32_t width, uint32_t he
     }
 }
 
+__global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { *p = v; }
+
 // UniformFloat::new_inclusive(low, high).scale (rand 0.9): (high-low)/max_rand, reduced by ulps until
 // scale*max_rand + low <= high
 float uniform_inclusive_scale(float low, float high) {
@@ -1039,6 +1041,11 @@ int launch_trace_rays(const DevScene& sc, const float* ox, const float* oy, cons
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(cu_count) * 8));
     hipLaunchKernelGGL(trace_rays_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), P);
     return check(hipGetLastError(), "trace_rays_kernel launch", err);
+}
+
+int launch_set_u64(unsigned long long* d_ptr, unsigned long long value, void* stream, std::string& err) {
+    hipLaunchKernelGGL(set_u64_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), d_ptr, value);
+    return check(hipGetLastError(), "set_u64_kernel launch", err);
 }
 
 int launch_generate_rays(const mp_camera_sampler& s, uint32_t width, uint32_t spp, uint64_t seed, mp_block block,

@@ -106,6 +106,7 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err);
 int launch_trace_rays(const DevScene& sc, const float* ox, const float* oy, const float* oz, const float* dx,
                       const float* dy, const float* dz, uint64_t n, const mp_hits_soa& hits, int cu_count, void* stream,
                       std::string& err);
+int launch_set_u64(unsigned long long* d_ptr, unsigned long long value, void* stream, std::string& err);
 int launch_generate_rays(const mp_camera_sampler& s, uint32_t width, uint32_t spp, uint64_t seed, mp_block block,
                          uint32_t sample, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz, void* stream,
                          std::string& err);
