@@ -60,11 +60,14 @@ def gather_shards(shard, plan: ShardPlan, rank: int, group=None, dst: int = 0):
 
 
 class DistributedFrame:
-    """Per-rank driver used by bench.py: render my shard in one launch, gather, un-tile on rank 0."""
+    """Per-rank driver used by bench.py: render my shard in one launch straight into the gather source buffer, gather
+    into one preallocated rank-major buffer on rank 0, un-tile there (padding slots are empty blocks the kernel skips).
+    Nothing is allocated per frame."""
 
     def __init__(self, scene, camera, settings, rank: int, world: int, tiles: Optional[Sequence[ScreenBlock]] = None):
         import torch
 
+        from . import _lib
         from .renderer import FrameRenderer
         from .screen_block import tile_ordering
 
@@ -72,15 +75,16 @@ class DistributedFrame:
         self.rank, self.world, self.settings = rank, world, settings
         self.all_tiles = list(tiles) if tiles is not None else tile_ordering(ScreenBlock(0, 0, w, h), settings.tile_size)
         self.plan = plan_shards(self.all_tiles, world)
-        self.renderer = FrameRenderer(scene, camera, settings, tiles=self.plan.shards[rank])
         ts = settings.tile_size
-        self.shard = torch.zeros((max(self.plan.per_rank, 1), ts, ts, 4), dtype=torch.float32, device=self.renderer.device)
-        self._keep = None
-        if rank == 0:
-            keep = self.plan.keep_indices()
-            self._tiles0 = [self.plan.gather_order[i] for i in keep]
-            if len(keep) != self.plan.world * self.plan.per_rank:
-                self._keep = torch.tensor(keep, device=self.renderer.device)
+        dev = torch.device("cuda", scene.object.ctx.device_id)
+        self.shard = torch.zeros((max(self.plan.per_rank, 1), ts, ts, 4), dtype=torch.float32, device=dev)
+        self.renderer = FrameRenderer(scene, camera, settings, tiles=self.plan.shards[rank], tile_buf=self.shard)
+        self._gather_buf = self._gather_views = self._order = None
+        if rank == 0 and world > 1:
+            self._gather_buf = torch.zeros((world * self.plan.per_rank, ts, ts, 4), dtype=torch.float32, device=dev)
+            self._gather_views = [self._gather_buf[r * self.plan.per_rank:(r + 1) * self.plan.per_rank] for r in range(world)]
+            order = self.plan.gather_order
+            self._order = (order, (_lib.Block * max(len(order), 1))(*[t.as_struct() for t in order]))
 
     @property
     def rays_per_frame_local(self) -> int:
@@ -92,18 +96,16 @@ class DistributedFrame:
     def step(self, want_u8: bool = True, kernel_events=None):
         """One frame: returns (image f32, image u8) on rank 0, (None, None) elsewhere.  kernel_events = (start, end)
         torch.cuda.Event pair recorded around the render launch on the current stream."""
+        import torch.distributed as dist
+
         if kernel_events is not None:
             kernel_events[0].record()
-        buf = self.render_local()
+        self.render_local()
         if kernel_events is not None:
             kernel_events[1].record()
         if self.world == 1:
-            return self.renderer.untile(want_u8=want_u8)
-        n = len(self.plan.shards[self.rank])
-        self.shard[:n].copy_(buf[:n])
-        cat = gather_shards(self.shard, self.plan, self.rank)
+            return self.renderer.untile(want_u8=want_u8, reuse=True)
+        dist.gather(self.shard, self._gather_views, dst=0)
         if self.rank != 0:
             return None, None
-        if self._keep is not None:
-            cat = cat.index_select(0, self._keep)
-        return self.renderer.untile(cat.contiguous(), self._tiles0, want_u8=want_u8)
+        return self.renderer.untile(self._gather_buf, self._order, want_u8=want_u8, reuse=True)

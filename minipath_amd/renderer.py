@@ -156,7 +156,8 @@ class FrameRenderer:
     stream (mp_render_tiles_device) and scatters them into an image (mp_untile).  Used by bench.py and by the
     multi-GPU driver; torch only provides the device memory and the stream."""
 
-    def __init__(self, scene: Scene, camera: Camera, settings: RenderSettings, tiles: Optional[Sequence[ScreenBlock]] = None):
+    def __init__(self, scene: Scene, camera: Camera, settings: RenderSettings, tiles: Optional[Sequence[ScreenBlock]] = None,
+                 tile_buf=None):
         import torch
 
         bvh = scene.object
@@ -171,7 +172,11 @@ class FrameRenderer:
         self._sampler = camera.build_sampler(settings.resolution).as_struct()
         self._st = settings.as_struct()
         ts = settings.tile_size
-        self.tile_buf = torch.zeros((max(len(self.tiles), 1), ts, ts, 4), dtype=torch.float32, device=self.device)
+        if tile_buf is None:
+            tile_buf = torch.zeros((max(len(self.tiles), 1), ts, ts, 4), dtype=torch.float32, device=self.device)
+        assert tile_buf.is_contiguous() and tile_buf.shape[0] >= len(self.tiles) and tuple(tile_buf.shape[1:]) == (ts, ts, 4)
+        self.tile_buf = tile_buf  # may be a caller-owned shard (multi-GPU gather source)
+        self._img = self._img8 = None
         self.samples_per_frame = sum(t.area() for t in self.tiles) * settings.sample_count
         self.rays_per_frame = self.samples_per_frame  # reference semantics: one Object::intersect per sample
         self.segments = torch.zeros(1, dtype=torch.int64, device=self.device)  # ray segments of the last launch
@@ -191,16 +196,29 @@ class FrameRenderer:
         )
         return self.tile_buf
 
-    def untile(self, tile_buf=None, tiles: Optional[Sequence[ScreenBlock]] = None, want_u8: bool = True):
-        """Tile-major -> image-major f32 (+ u8 via color_to_image) on the device."""
+    def untile(self, tile_buf=None, tiles: Optional[Sequence[ScreenBlock]] = None, want_u8: bool = True, reuse: bool = False):
+        """Tile-major -> image-major f32 (+ u8 via color_to_image) on the device.  Empty blocks in `tiles` (padding of
+        equal-size multi-GPU shards) are skipped by the kernel.  reuse=True writes into this renderer's cached frame
+        buffers instead of allocating new ones (every pixel a tile covers is overwritten)."""
         import torch
 
         w, h = self.settings.resolution
         buf = self.tile_buf if tile_buf is None else tile_buf
-        tl = self.tiles if tiles is None else list(tiles)
-        tiles_c = self._tiles_c if tiles is None else (_lib.Block * max(len(tl), 1))(*[t.as_struct() for t in tl])
-        img = torch.zeros((h, w, 4), dtype=torch.float32, device=self.device)
-        img8 = torch.zeros((h, w, 4), dtype=torch.uint8, device=self.device) if want_u8 else None
+        tl = self.tiles if tiles is None else tiles
+        if tiles is None:
+            tiles_c = self._tiles_c
+        elif isinstance(tiles, tuple) and len(tiles) == 2 and not isinstance(tiles[0], ScreenBlock):
+            tl, tiles_c = tiles  # (list, prebuilt ctypes array)
+        else:
+            tl = list(tiles)
+            tiles_c = (_lib.Block * max(len(tl), 1))(*[t.as_struct() for t in tl])
+        if reuse and self._img is not None:
+            img, img8 = self._img, (self._img8 if want_u8 else None)
+        else:
+            img = torch.zeros((h, w, 4), dtype=torch.float32, device=self.device)
+            img8 = torch.zeros((h, w, 4), dtype=torch.uint8, device=self.device) if want_u8 else None
+            if reuse:
+                self._img, self._img8 = img, img8
         _lib.check(
             _lib.lib().mp_untile(
                 self.ctx.handle, C.byref(self._st), tiles_c, len(tl), buf.data_ptr(), img.data_ptr(),

@@ -490,3 +490,31 @@ def test_reference_mode_segment_count(teapot):
     assert int(fr.segments.item()) == 256 * 256 * 3 == fr.rays_per_frame
     with pytest.raises(ValueError):
         mp.RenderSettings(64, 1, (8, 8), traversal="nope").as_struct()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_render_reassembles_to_single_gpu_image(teapot, world):
+    """SURVEY 8e on one device: every rank's shard rendered by its own launch into the gather layout (equal-size shards,
+    empty padding blocks), rank-major concatenation, un-tile with the padded tile list == the one-GPU frame, bit for bit.
+    (The RCCL gather itself is the only step not exercised; the same plan is exercised over gloo in test_distributed_cpu.)"""
+    import torch
+
+    from minipath_amd import _lib
+    from minipath_amd.distributed import plan_shards
+
+    cam = mp.Camera.teapot_view()
+    st = mp.RenderSettings(32, 4, (200, 120), seed=SEED)
+    ref = mp.FrameRenderer(teapot, cam, st)
+    ref.render()
+    ref_img, ref_u8 = ref.untile()
+    plan = plan_shards(ref.tiles, world)
+    ts = st.tile_size
+    gather = torch.zeros((world * plan.per_rank, ts, ts, 4), dtype=torch.float32, device="cuda")
+    for r in range(world):
+        shard = gather[r * plan.per_rank:(r + 1) * plan.per_rank]
+        mp.FrameRenderer(teapot, cam, st, tiles=plan.shards[r], tile_buf=shard).render()
+    order = plan.gather_order
+    order_c = (_lib.Block * len(order))(*[t.as_struct() for t in order])
+    img, img8 = ref.untile(gather, (order, order_c), reuse=False)
+    torch.cuda.synchronize()
+    assert torch.equal(img.view(torch.int32), ref_img.view(torch.int32)) and torch.equal(img8, ref_u8)
