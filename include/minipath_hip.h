@@ -148,6 +148,8 @@ int mp_scene_from_obj(mp_ctx *ctx, const char *path, mp_scene **out);
  * normals/tex may be NULL (=> zero normals => flat shading, building.rs:200). */
 int mp_scene_from_triangles(mp_ctx *ctx, const float *positions, const float *normals, const float *tex,
                             uint32_t vertex_count, const uint32_t *indices, uint32_t triangle_count, mp_scene **out);
+/* scene/primitives.rs:10-56 Sphere as the scene's Object (analytic intersection, no BVH).  ctx may be NULL (host-only). */
+int mp_scene_sphere(mp_ctx *ctx, const float center[3], float radius, mp_scene **out);
 void mp_scene_destroy(mp_scene *scene);
 int mp_scene_info_get(const mp_scene *scene, mp_scene_info *out);
 /* Export of the reference-layout arrays (for parity checks and for a Rust caller that wants to rebuild a

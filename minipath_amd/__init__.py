@@ -7,11 +7,11 @@ All compute happens in ``csrc/libminipath_hip.so`` (hand-written HIP kernels); t
 from ._lib import MinipathError, MP_NO_PRIM, MP_LINK_NULL, SO_PATH  # noqa: F401
 from .camera import Camera, CameraSampler  # noqa: F401
 from .screen_block import ScreenBlock, tile_ordering  # noqa: F401
-from .scene import Context, Scene, TriangleBvh  # noqa: F401
+from .scene import Context, Scene, Sphere, TriangleBvh  # noqa: F401
 from .renderer import RenderProgress, RenderProgressSnapshot, RenderSettings, render, render_tile, FrameRenderer  # noqa: F401
 
 __all__ = [
     "Camera", "CameraSampler", "Context", "FrameRenderer", "MinipathError", "RenderProgress",
-    "RenderProgressSnapshot", "RenderSettings", "Scene", "ScreenBlock", "TriangleBvh", "render", "render_tile",
+    "RenderProgressSnapshot", "RenderSettings", "Scene", "ScreenBlock", "Sphere", "TriangleBvh", "render", "render_tile",
     "tile_ordering",
 ]

@@ -390,6 +390,22 @@ int mp_scene_from_triangles(mp_ctx* ctx, const float* positions, const float* no
     return finish_scene(ctx, std::move(s), out);
 }
 
+int mp_scene_sphere(mp_ctx* ctx, const float center[3], float radius, mp_scene** out) {
+    if (!center || !out) return fail(MP_ERR_INVALID, "NULL argument");
+    auto s = std::make_unique<mp_scene>();
+    s->ctx = ctx;
+    s->dev.kind = 1;
+    for (int k = 0; k < 3; k++) {
+        s->dev.sphere_center[k] = center[k];
+        s->host.bbox.mn[k] = center[k] - radius;  // get_bounding_box, primitives.rs:50-56
+        s->host.bbox.mx[k] = center[k] + radius;
+    }
+    s->dev.sphere_radius = radius;
+    s->dev.stack_cap = 1;
+    *out = s.release();
+    return MP_OK;
+}
+
 void mp_scene_destroy(mp_scene* s) {
     if (!s) return;
     if (s->ctx) {

@@ -332,6 +332,25 @@ __device__ __forceinline__ void resolve_normal(const DevScene& sc, uint32_t prim
     n[0] = nx / len; n[1] = ny / len; n[2] = nz / len;
 }
 
+// impl Object for Sphere::intersect, scene/primitives.rs:16-48 (lane-parallel; n = unit normal at the hit)
+__device__ __forceinline__ bool sphere_intersect(const DevScene& sc, const Ray& r, float& t, float n[3]) {
+    const float ocx = r.ox - sc.sphere_center[0], ocy = r.oy - sc.sphere_center[1], ocz = r.oz - sc.sphere_center[2];
+    const float b = ocx * r.dx + ocy * r.dy + ocz * r.dz;
+    const float c = (ocx * ocx + ocy * ocy + ocz * ocz) - sc.sphere_radius * sc.sphere_radius;
+    const float disc = b * b - c;
+    if (disc < 0.0f) return false;
+    const float sq = sqrtf(disc);
+    const float t1 = -b - sq, t2 = -b + sq;
+    if (t1 > 0.0f) t = t1;
+    else if (t2 > 0.0f) t = t2;
+    else return false;
+    const float px = r.ox + r.dx * t, py = r.oy + r.dy * t, pz = r.oz + r.dz * t;
+    const float nx = px - sc.sphere_center[0], ny = py - sc.sphere_center[1], nz = pz - sc.sphere_center[2];
+    const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    n[0] = nx / len; n[1] = ny / len; n[2] = nz / len;
+    return true;
+}
+
 // ---- fused tile render: Worker::render_tile (worker.rs:32-49) for a list of tiles -----------------------------
 struct RenderParams {
     DevScene scene;
@@ -380,6 +399,16 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
             Ray r;
             r.dx = r.dy = r.dz = 0.0f;
             if (act) sample_ray(P.gen, px, py, s, r);
+            if (P.scene.kind == 1u) {  // Scene<Sphere>: no traversal, everything is lane-parallel
+                float c = 0.0f, h = 0.0f, ts_, nn[3];
+                if (act && sphere_intersect(P.scene, r, ts_, nn)) { c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]); h = 1.0f; }
+#pragma unroll
+                for (int j = 0; j < S; j++) {
+                    acc += __shfl(c, (lane & ~(S - 1)) + j);
+                    cnt += __shfl(h, (lane & ~(S - 1)) + j);
+                }
+                continue;
+            }
             // compaction of the lanes whose ray can reach the scene into the wave's ray queue
             const bool queued = act && may_hit_scene(P.scene, r);
             const uint64_t am = __ballot(queued);
@@ -666,7 +695,7 @@ __global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P
             Ray r;
             r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
             if (act) sample_ray(P.gen, px, py, s, r);
-            const bool go = act && may_hit_scene(P.scene, r);
+            const bool go = act && P.scene.kind == 0u && may_hit_scene(P.scene, r);
             PacketHit h;
             h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
             if (__ballot(go) != 0) {
@@ -680,11 +709,15 @@ __global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P
                 }
             }
             float c = 0.0f;
-            const bool hit = h.prim != kNoPrim;
+            bool hit = h.prim != kNoPrim;
             if (hit) {
                 float nn[3];
                 resolve_normal(P.scene, h.prim, h.u, h.v, nn);
                 c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60
+            } else if (P.scene.kind == 1u) {  // Scene<Sphere>
+                float ts_, nn[3];
+                hit = act && sphere_intersect(P.scene, r, ts_, nn);
+                if (hit) c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);
             }
             // alpha sums 1.0 per hit: an exact integer in f32, so the order is irrelevant
             cnt += static_cast<float>(__popcll(__ballot(hit) & pixel_lanes));
@@ -851,6 +884,24 @@ __global__ __launch_bounds__(256) void trace_rays_kernel(TraceParams P) {
         Ray r;
         r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
         if (act) ray_new(P.ox[i], P.oy[i], P.oz[i], P.dx[i], P.dy[i], P.dz[i], r);
+        if (P.scene.kind == 1u) {  // Sphere: HitRecord{t, point, normal, material 0, texture_coords origin} (primitives.rs:40-46)
+            if (act) {
+                float t = FLT_MAX, nn[3] = {0, 0, 0};
+                const bool hit = sphere_intersect(P.scene, r, t, nn);
+                if (!hit) t = FLT_MAX;
+                if (P.hits.d_t) P.hits.d_t[i] = t;
+                if (P.hits.d_prim) P.hits.d_prim[i] = hit ? 0u : kNoPrim;
+                if (P.hits.d_u) P.hits.d_u[i] = 0.0f;
+                if (P.hits.d_v) P.hits.d_v[i] = 0.0f;
+                for (int k = 0; k < 3; k++) {
+                    const float o = k == 0 ? r.ox : k == 1 ? r.oy : r.oz, d = k == 0 ? r.dx : k == 1 ? r.dy : r.dz;
+                    if (P.hits.d_point) P.hits.d_point[i * 3 + k] = hit ? o + d * t : 0.0f;
+                    if (P.hits.d_normal) P.hits.d_normal[i * 3 + k] = hit ? nn[k] : 0.0f;
+                    if (P.hits.d_tex) P.hits.d_tex[i * 3 + k] = 0.0f;
+                }
+            }
+            continue;
+        }
         const bool queued = act && may_hit_scene(P.scene, r);
         const uint64_t am = __ballot(queued);
         const int n = __popcll(am), rank = __popcll(am & ((1ull << lane) - 1ull));
@@ -987,6 +1038,7 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     if (rc) return rc;
     const uint64_t units = static_cast<uint64_t>(L.n_tiles) * ((L.tile_size + 7) / 8) * ((L.tile_size + 7) / 8);
     const uint64_t want = (units + 3) / 4;
+    if (L.max_depth > 0 && L.scene.kind != 0u) { err = "the path extension is defined for TriangleBvh scenes only"; return MP_ERR_UNSUPPORTED; }
     if (L.max_depth > 0) {  // build-defined path extension
         const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / lds));
         const int S = L.spp >= 8 ? 8 : L.spp >= 4 ? 4 : L.spp >= 2 ? 2 : 1;

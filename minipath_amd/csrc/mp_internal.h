@@ -62,6 +62,9 @@ int load_obj(const char* path, std::vector<float>& pos, std::vector<float>& nrm,
 // shade : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) pad pad.  48 B per triangle slot.
 // vidx/vtex : for the full HitRecord (texture_coords).
 struct DevScene {
+    uint32_t kind = 0;               // 0 = TriangleBvh, 1 = Sphere (scene/primitives.rs:10-13)
+    float sphere_center[3] = {0, 0, 0};
+    float sphere_radius = 0;
     const float* nodes = nullptr;
     const float* tris = nullptr;
     const float* shade = nullptr;

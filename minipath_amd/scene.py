@@ -143,6 +143,17 @@ class TriangleBvh:
             pass
 
 
+class Sphere(TriangleBvh):
+    """scene/primitives.rs:10-56: analytic sphere as the scene's Object (same handle type, no BVH arrays)."""
+
+    def __init__(self, center, radius: float, ctx: Optional[Context] = None):
+        h = C.c_void_p()
+        c = (C.c_float * 3)(*[float(v) for v in center])
+        _lib.check(_lib.lib().mp_scene_sphere(ctx.handle if ctx else None, c, C.c_float(radius), C.byref(h)))
+        super().__init__(h, ctx)
+        self.center, self.radius = tuple(float(v) for v in center), float(radius)
+
+
 class Scene:
     """scene/mod.rs:12-15: Scene { object }."""
 

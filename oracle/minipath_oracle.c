@@ -1149,6 +1149,59 @@ static void render_sample_impl(const mpo_bvh *b, const mpo_sampler *s, uint32_t 
     }
 }
 
+/* ---- scene/primitives.rs:15-56 : Sphere ------------------------------------------------------------------------ */
+void mpo_sphere_intersect(const float center[3], float radius, const mpo_ray *ray, mpo_hit *out) {
+    memset(out, 0, sizeof(*out));
+    out->prim = MPO_NO_TRIANGLE;
+    out->t = FLT_MAX;
+    float oc[3] = {ray->o[0] - center[0], ray->o[1] - center[1], ray->o[2] - center[2]}; /* :17 */
+    float b = dot3(oc, ray->d);                                                          /* :18 */
+    float c = dot3(oc, oc) - radius * radius;                                            /* :19 */
+    float disc = b * b - c;                                                              /* :20 */
+    if (disc < 0.0f) return;                                                             /* :22-24 */
+    float sq = sqrtf(disc);
+    float t1 = -b - sq, t2 = -b + sq, t;                                                 /* :27-28 */
+    if (t1 > 0.0f) t = t1;
+    else if (t2 > 0.0f) t = t2;
+    else return;                                                                         /* :29-35 */
+    out->hit = 1;
+    out->t = t;
+    out->prim = 0;
+    mpo_ray_point_at(ray, t, out->point);                                                /* :37 */
+    float n[3] = {out->point[0] - center[0], out->point[1] - center[1], out->point[2] - center[2]};
+    normalize3(n, out->normal);                                                          /* :38 */
+}
+
+/* render_tile (worker.rs:32-49) over Scene<Sphere> */
+void mpo_render_tile_sphere(const float center[3], float radius, const mpo_sampler *s, uint32_t width, uint32_t spp,
+                            uint64_t seed, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, float *rgba_f32, uint8_t *rgba_u8) {
+    float inv = 1.0f / (float)spp;
+    size_t tw = x1 - x0;
+    for (uint32_t y = y0; y < y1; y++)
+        for (uint32_t x = x0; x < x1; x++) {
+            float sum[4] = {0, 0, 0, 0};
+            for (uint32_t i = 0; i < spp; i++) {
+                mpo_rng rng;
+                mpo_rng_seed(&rng, mpo_sample_key(seed, width, spp, x, y, i));
+                mpo_ray ray;
+                mpo_sample_ray(s, x, y, &rng, &ray);
+                mpo_hit h;
+                mpo_sphere_intersect(center, radius, &ray, &h);
+                if (h.hit) {
+                    float d = fabsf(ray.d[0] * h.normal[0] + ray.d[1] * h.normal[1] + ray.d[2] * h.normal[2]);
+                    sum[0] += d; sum[1] += d; sum[2] += d; sum[3] += 1.0f;
+                } else {
+                    for (int k = 0; k < 4; k++) sum[k] += 0.0f;
+                }
+            }
+            float px[4];
+            for (int k = 0; k < 4; k++) px[k] = sum[k] * inv;
+            size_t o = ((size_t)(y - y0) * tw + (x - x0)) * 4;
+            if (rgba_f32) memcpy(rgba_f32 + o, px, 16);
+            if (rgba_u8) mpo_color_to_image(px, rgba_u8 + o);
+        }
+}
+
 /* ---- build-defined path extension (NO reference counterpart: the reference has no bounce loop) --------
  * Diffuse grey surfaces (albedo 0.75) under a uniform white sky, paths of at most max_depth segments:
  *   L = 0, throughput = 1; for depth = 1..max_depth: trace; miss -> L = throughput (sky radiance 1), stop;

@@ -193,6 +193,11 @@ double mpo_render_image_mt(const mpo_bvh *b, const mpo_sampler *s, uint32_t widt
                            uint64_t seed, uint32_t tile, int nthreads, size_t max_tiles, size_t tile_stride,
                            float *rgba_f32, uint8_t *rgba_u8, uint64_t *rays_out, mpo_counters *cnt);
 
+/* ---- scene/primitives.rs : Sphere (Object::intersect :16-48) ----------------------------------------------------- */
+void mpo_sphere_intersect(const float center[3], float radius, const mpo_ray *ray, mpo_hit *out);
+void mpo_render_tile_sphere(const float center[3], float radius, const mpo_sampler *s, uint32_t width, uint32_t spp,
+                            uint64_t seed, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, float *rgba_f32, uint8_t *rgba_u8);
+
 /* ---- build-defined path extension (no reference counterpart; see the .c file) ------------------------------ */
 void mpo_render_sample_paths(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t spp, uint64_t seed, uint32_t x,
                              uint32_t y, uint32_t sample, uint32_t max_depth, float rgba[4], uint64_t *segments);

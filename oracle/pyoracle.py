@@ -172,6 +172,11 @@ def lib() -> C.CDLL:
         C.c_size_t, C.c_size_t, f32p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.POINTER(Counters),
     ]
     L.mpo_render_image_mt.restype = C.c_double
+    L.mpo_sphere_intersect.argtypes = [f32p, C.c_float, C.POINTER(Ray), C.POINTER(Hit)]
+    L.mpo_render_tile_sphere.argtypes = [
+        f32p, C.c_float, C.POINTER(Sampler), C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+        f32p, C.POINTER(C.c_uint8),
+    ]
     L.mpo_render_tile_paths.argtypes = [
         C.c_void_p, C.POINTER(Sampler), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32,
         C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64),
@@ -404,6 +409,20 @@ class Bvh:
             _f32p(f), u8.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(rays), C.byref(cnt) if want_counters else None,
         )
         return f, u8, secs, rays.value, cnt
+
+
+def sphere_intersect(center, radius, ray: Ray) -> Hit:
+    h = Hit()
+    lib().mpo_sphere_intersect(vec3(*center), C.c_float(radius), C.byref(ray), C.byref(h))
+    return h
+
+
+def render_tile_sphere(center, radius, sampler: Sampler, width, spp, seed, x0, y0, x1, y1):
+    f = np.zeros((y1 - y0, x1 - x0, 4), np.float32)
+    u8 = np.zeros((y1 - y0, x1 - x0, 4), np.uint8)
+    lib().mpo_render_tile_sphere(vec3(*center), C.c_float(radius), C.byref(sampler), width, spp, C.c_uint64(seed), x0, y0, x1, y1,
+                                 _f32p(f), u8.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return f, u8
 
 
 def sample_ray(sampler: Sampler, x: int, y: int, key: int) -> Ray:

@@ -518,3 +518,46 @@ def test_sharded_render_reassembles_to_single_gpu_image(teapot, world):
     img, img8 = ref.untile(gather, (order, order_c), reuse=False)
     torch.cuda.synchronize()
     assert torch.equal(img.view(torch.int32), ref_img.view(torch.int32)) and torch.equal(img8, ref_u8)
+
+
+def test_sphere_object(ctx, oracle):
+    """scene/primitives.rs: Sphere as the scene's Object -- the reference's three known answers (:62-97) through
+    mp_trace_rays, random rays vs the oracle (bit-exact t / point / normal), and render_tile parity in both kernels."""
+    import torch
+
+    sph = mp.Sphere((1.0, 2.0, 3.0), 1.0, ctx)
+    o = torch.tensor([[1.0, 2.0, 0.0], [2.0, 2.0, 0.0], [2.0, 2.01, 0.0]], device="cuda")
+    d = torch.tensor([[0.0, 0.0, 1.0]] * 3, device="cuda")
+    out = sph.intersect(o, d, full=True)
+    t = out["t"].cpu().numpy()
+    assert abs(t[0] - 2.0) < 1e-6 and abs(t[1] - 3.0) < 1e-6 and out["prim"].cpu().numpy().view(np.uint32)[2] == 0xFFFFFFFF
+    bmin, bmax = sph.get_bounding_box()
+    assert np.allclose(bmin, [0, 1, 2]) and np.allclose(bmax, [2, 3, 4])
+    ro, rd = meshes.random_rays(5000, 3, bmin, bmax)
+    out = sph.intersect(torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda(), full=True)
+    got = {k: v.cpu().numpy() for k, v in out.items()}
+    nh = 0
+    for i in range(0, 5000, 7):
+        h = oracle.sphere_intersect((1.0, 2.0, 3.0), 1.0, oracle.ray_new(ro[i], rd[i]))
+        assert (got["prim"].view(np.uint32)[i] != 0xFFFFFFFF) == bool(h.hit)
+        if h.hit:
+            nh += 1
+            assert bits(got["t"][i:i + 1])[0] == bits(np.array([h.t], np.float32))[0]
+            assert np.array_equal(bits(got["normal"][i]), bits(np.array(list(h.normal), np.float32)))
+            assert np.array_equal(bits(got["point"][i]), bits(np.array(list(h.point), np.float32)))
+    assert nh > 50
+    cam = mp.Camera.default().look_at((1.0, 2.0, -4.0), (1.0, 2.0, 3.0), (0, 1, 0)).f_number(2.0)
+    oc = oracle.Camera()
+    import ctypes as C
+    oracle.lib().mpo_camera_default(C.byref(oc))
+    oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(1.0, 2.0, -4.0), oracle.vec3(1.0, 2.0, 3.0), oracle.vec3(0, 1, 0))
+    oc.f_number = 2.0
+    for traversal in ("packets", "groups"):
+        st = mp.RenderSettings(64, 5, (128, 128), seed=9, traversal=traversal)
+        f, u8 = mp.render_tile(mp.Scene(sph), cam.build_sampler((128, 128)), st, mp.ScreenBlock(32, 32, 96, 96))
+        of, ou8 = oracle.render_tile_sphere((1.0, 2.0, 3.0), 1.0, oracle.build_sampler(oc, 128, 128), 128, 5, 9, 32, 32, 96, 96)
+        assert np.array_equal(bits(f), bits(of)) and np.array_equal(u8, ou8)
+        assert (of[..., 3] > 0).mean() > 0.2
+    with pytest.raises(mp.MinipathError) as e:  # the build-defined path extension is specified for TriangleBvh only
+        mp.render_tile(mp.Scene(sph), cam.build_sampler((128, 128)), mp.RenderSettings(64, 1, (128, 128), max_depth=2), mp.ScreenBlock(0, 0, 64, 64))
+    assert e.value.code == 5

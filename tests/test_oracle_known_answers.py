@@ -334,3 +334,18 @@ def test_color_to_image(oracle):
     assert list(out) == [1, 2, 255, 0]
     L.mpo_color_to_image((C.c_float * 4)(float("nan"), 1.0, 0.0, 0.49 / 255.0), out)
     assert list(out) == [0, 255, 0, 0]
+
+
+def test_sphere_known_answers(oracle):
+    """scene/primitives.rs:62-97: direct hit t = 2, grazing hit t = 3, narrow miss."""
+    h = oracle.sphere_intersect((1.0, 2.0, 3.0), 1.0, oracle.ray_new((1.0, 2.0, 0.0), (0.0, 0.0, 1.0)))
+    assert h.hit == 1 and abs(h.t - 2.0) < 1e-6
+    assert np.allclose(list(h.normal), [0, 0, -1]) and np.allclose(list(h.point), [1, 2, 2])
+    h = oracle.sphere_intersect((1.0, 2.0, 3.0), 1.0, oracle.ray_new((2.0, 2.0, 0.0), (0.0, 0.0, 1.0)))
+    assert h.hit == 1 and abs(h.t - 3.0) < 1e-6
+    h = oracle.sphere_intersect((1.0, 2.0, 3.0), 1.0, oracle.ray_new((2.0, 2.01, 0.0), (0.0, 0.0, 1.0)))
+    assert h.hit == 0
+    # inside the sphere: t1 <= 0 < t2 ; behind the origin: None
+    h = oracle.sphere_intersect((0.0, 0.0, 0.0), 2.0, oracle.ray_new((0.0, 0.0, 0.0), (1.0, 0.0, 0.0)))
+    assert h.hit == 1 and h.t == 2.0
+    assert oracle.sphere_intersect((0.0, 0.0, -5.0), 1.0, oracle.ray_new((0.0, 0.0, 0.0), (0.0, 0.0, 1.0))).hit == 0
