@@ -243,16 +243,33 @@ def test_render_async_api(teapot, oracle, teapot_oracle_bvh):
 
 
 def test_render_abort(teapot):
-    """RenderProgress::abort (machinery.rs:159-165): in-flight tiles finish, no new ones start."""
+    """RenderProgress::abort (machinery.rs:159-165): in-flight tiles finish, no new ones start.  abort() is called
+    from the first `started` callback, i.e. while the first batch of tiles is in flight: exactly that batch completes."""
     cam = mp.Camera.teapot_view()
-    st = mp.RenderSettings(8, 64, (1024, 1024), seed=1)  # 16384 tiles, many batches
-    rp = mp.render(teapot, cam, st)
-    rp.abort()
+    st = mp.RenderSettings(8, 2, (2048, 2048), seed=1)  # 65 536 tiles = several launch batches
+    box = {}
+
+    def on_start(t):
+        if "rp" in box and not box.get("aborted"):
+            box["aborted"] = True
+            box["rp"].abort()
+
+    import time
+
+    rp = mp.render(teapot, cam, st, on_start)
+    box["rp"] = rp
+    t0 = time.time()
+    while not box.get("aborted") and not rp.is_finished() and time.time() - t0 < 30:
+        time.sleep(0.0005)
     rp.wait()
     p = rp.progress()
-    assert rp.is_finished() and p.finished < p.total
+    assert rp.is_finished() and box.get("aborted")
+    assert 0 < p.finished < p.total == 65536
     img = rp.image()
-    assert img.shape == (1024, 1024, 4)
+    assert img.shape == (2048, 2048, 4)
+    # aborting a finished render is harmless
+    rp.abort()
+    assert rp.progress().finished == p.finished
 
 
 def test_untile_color_to_image(ctx, teapot, oracle):
