@@ -140,7 +140,7 @@ int upload_scene(mp_scene* s) {
             for (int k = 0; k < 6; k++) nodes_aos[n * 64 + i * 8 + k] = nodes[n * kNodeDwords + k * 8 + i];
             nodes_aos[n * 64 + i * 8 + 6] = nodes[n * kNodeDwords + 48 + i];
         }
-    std::vector<float> tris_aos(np * 96 + 12, 0.0f);  // + one triangle of tail padding (prefetch)
+    std::vector<float> tris_aos(np * 96 + 36, 0.0f);  // + tail padding: the triangle loop prefetches up to two ahead
     std::vector<uint32_t> pkt_valid(np, 0);
     for (size_t p = 0; p < np; p++)
         for (int i = 0; i < 8; i++) {

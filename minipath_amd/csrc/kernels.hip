@@ -467,7 +467,8 @@ constexpr float kHuge = 1099511627776.0f;        // 2^40
 // (|num| >= 2^-40 and |det| <= 2^40 keep |quotient| >= 2^-80(1-eps): no underflow to -0, which would pass `>= 0`).
 // det = +-0 or subnormal gives an infinite reciprocal whose sign still follows det.  NaN never rejects.
 __device__ __forceinline__ bool surely_negative(float num, float det) {
-    return (((as_u(num) ^ as_u(det)) >> 31) != 0u) && (fabsf(num) >= kTiny) && (fabsf(det) <= kHuge);
+    // bitwise & on purpose: three lane masks ANDed on the scalar unit, no short-circuit control flow
+    return (static_cast<int>(as_u(num) ^ as_u(det)) < 0) & (fabsf(num) >= kTiny) & (fabsf(det) <= kHuge);
 }
 
 template <bool PATCH_NAN>
@@ -621,35 +622,47 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
             const uint32_t first = link >> 3, count = link & 7u;
             const uint32_t n_real = (count - 1u) * 8u + __builtin_amdgcn_readfirstlane(nvalid[first + count - 1u]);
             kfp tp = tris + static_cast<size_t>(first) * 96;
-            bool changed = false;
-            float v0x = tp[0], v0y = tp[1], v0z = tp[2], e1x = tp[3], e1y = tp[4], e1z = tp[5], e2x = tp[6], e2y = tp[7], e2z = tp[8];
-            for (uint32_t i = 0; i < n_real; i++) {
-                tp += 12;  // prefetch of the next triangle (the array has one triangle of tail padding)
-                const float n0 = tp[0], n1 = tp[1], n2 = tp[2], n3 = tp[3], n4 = tp[4], n5 = tp[5], n6 = tp[6], n7 = tp[7], n8 = tp[8];
+            uint64_t changed = 0;  // lanes that accepted a hit in this leaf
+            // One triangle test; all predicates are lane masks combined with `&` (no short-circuit control flow).
+            auto test = [&](const float v0x, const float v0y, const float v0z, const float e1x, const float e1y, const float e1z,
+                            const float e2x, const float e2y, const float e2z, const uint32_t tri) {
                 // triangle.rs:183-217
-                float hx = fms(r.dy, e2z, r.dz * e2y), hy = fms(r.dz, e2x, r.dx * e2z), hz = fms(r.dx, e2y, r.dy * e2x);
-                float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
-                float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
-                float un = fma_dot(sx, sy, sz, hx, hy, hz);
-                bool possible = on && !surely_negative(un, det);  // u >= 0 cannot hold otherwise
-                if (__ballot(possible) != 0) {
-                    float qx = fms(sy, e1z, sz * e1y), qy = fms(sz, e1x, sx * e1z), qz = fms(sx, e1y, sy * e1x);
-                    float vn = fma_dot(r.dx, r.dy, r.dz, qx, qy, qz);
-                    float tn = fma_dot(e2x, e2y, e2z, qx, qy, qz);
-                    possible = possible && !surely_negative(vn, det) && !surely_negative(tn, det);  // v >= 0, t >= 0
-                    if (__ballot(possible) != 0) {
-                        float inv_det = 1.0f / det;
-                        float u = inv_det * un, v = inv_det * vn, t = inv_det * tn;
-                        // mask & t>=0 & t<=max_t (:125), strict `<` vs the leaf best, then vs the global best (:129,:59):
-                        // equivalent to a running strict `<` against best.t (best.t never exceeds max_t)
-                        bool acc = on && (u >= 0.0f) && (v >= 0.0f) && ((u + v) <= 1.0f) && (t >= 0.0f) && (t < best_t);
-                        if (acc) { best_t = t; bu = u; bv = v; bprim = first * 8u + i; }
-                        changed = changed || acc;
-                    }
-                }
-                v0x = n0; v0y = n1; v0z = n2; e1x = n3; e1y = n4; e1z = n5; e2x = n6; e2y = n7; e2z = n8;
+                const float hx = fms(r.dy, e2z, r.dz * e2y), hy = fms(r.dz, e2x, r.dx * e2z), hz = fms(r.dx, e2y, r.dy * e2x);
+                const float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
+                const float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
+                const float un = fma_dot(sx, sy, sz, hx, hy, hz);
+                const bool rej_u = surely_negative(un, det);  // u >= 0 cannot hold
+                if (__builtin_amdgcn_ballot_w64(on & !rej_u) == 0) return;
+                const float qx = fms(sy, e1z, sz * e1y), qy = fms(sz, e1x, sx * e1z), qz = fms(sx, e1y, sy * e1x);
+                const float vn = fma_dot(r.dx, r.dy, r.dz, qx, qy, qz);
+                const float tn = fma_dot(e2x, e2y, e2z, qx, qy, qz);
+                const bool rej_vt = surely_negative(vn, det) | surely_negative(tn, det);  // v >= 0 / t >= 0 cannot hold
+                if (__builtin_amdgcn_ballot_w64(on & !rej_u & !rej_vt) == 0) return;
+                const float inv_det = 1.0f / det;
+                const float u = inv_det * un, v = inv_det * vn, t = inv_det * tn;
+                // mask & t>=0 & t<=max_t (:125), strict `<` vs the leaf best, then vs the global best (:129,:59):
+                // equivalent to a running strict `<` against best.t (best.t never exceeds max_t)
+                const bool acc = on & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) & (t >= 0.0f) & (t < best_t);
+                best_t = acc ? t : best_t;
+                bu = acc ? u : bu;
+                bv = acc ? v : bv;
+                bprim = acc ? tri : bprim;
+                changed |= __builtin_amdgcn_ballot_w64(acc);
+            };
+            // two register sets (A, B) alternate: B is fetched while A is tested and vice versa (the array has tail padding)
+            float a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3], a4 = tp[4], a5 = tp[5], a6 = tp[6], a7 = tp[7], a8 = tp[8];
+            uint32_t i = 0;
+            const uint32_t base = first * 8u;
+            for (;;) {
+                const float b0 = tp[12], b1 = tp[13], b2 = tp[14], b3 = tp[15], b4 = tp[16], b5 = tp[17], b6 = tp[18], b7 = tp[19], b8 = tp[20];
+                test(a0, a1, a2, a3, a4, a5, a6, a7, a8, base + i);
+                if (++i == n_real) break;
+                a0 = tp[24]; a1 = tp[25]; a2 = tp[26]; a3 = tp[27]; a4 = tp[28]; a5 = tp[29]; a6 = tp[30]; a7 = tp[31]; a8 = tp[32];
+                test(b0, b1, b2, b3, b4, b5, b6, b7, b8, base + i);
+                if (++i == n_real) break;
+                tp += 24;
             }
-            if (__ballot(changed) != 0) st.all_stale();  // every entry still on the stack predates this change
+            if (changed != 0) st.all_stale();  // every entry still on the stack predates this change
         }
     }
     hit.t = best_t; hit.u = bu; hit.v = bv; hit.prim = bprim;
