@@ -463,6 +463,18 @@ typedef const __attribute__((address_space(4))) uint32_t* kup;
 constexpr float kTiny = 9.094947017729282e-13f;  // 2^-40
 constexpr float kHuge = 1099511627776.0f;        // 2^40
 
+// Lane masks straight from the compare unit (v_cmp writes the 64-bit mask; no bool -> int -> ballot round trip, which costs two
+// VALU per use): LLVM CmpInst predicate numbers.
+constexpr int kFcmpOGE = 3, kFcmpOLE = 5, kIcmpSLT = 40;
+__device__ __forceinline__ uint64_t mask_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOLE); }
+__device__ __forceinline__ uint64_t mask_ge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOGE); }
+__device__ __forceinline__ uint64_t mask_neg(int a) { return __builtin_amdgcn_sicmp(a, 0, kIcmpSLT); }
+
+// surely_negative() as a lane mask
+__device__ __forceinline__ uint64_t surely_negative_mask(float num, float det) {
+    return mask_neg(static_cast<int>(as_u(num) ^ as_u(det))) & mask_ge(fabsf(num), kTiny) & mask_le(fabsf(det), kHuge);
+}
+
 // True when sign(num) != sign(det) and the quotient fl(fl(1/det) * num) is certainly a non-zero negative number
 // (|num| >= 2^-40 and |det| <= 2^40 keep |quotient| >= 2^-80(1-eps): no underflow to -0, which would pass `>= 0`).
 // det = +-0 or subnormal gives an infinite reciprocal whose sign still follows det.  NaN never rejects.
@@ -597,7 +609,8 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
             const float node_t1 = slab_entry<PATCH_NAN>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], r);
             on = on && !(node_t1 > best_t);
         }
-        if (__ballot(on) == 0) continue;
+        const uint64_t onm = __builtin_amdgcn_ballot_w64(on);
+        if (onm == 0) continue;
         if ((link & 7u) == 0u) {
             // InnerNode::intersect :149-162, children ascending
             const uint32_t node = link >> 3;
@@ -609,7 +622,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 float t1, t2;
                 slab<PATCH_NAN>(nd[c * 8 + 0], nd[c * 8 + 1], nd[c * 8 + 2], nd[c * 8 + 3], nd[c * 8 + 4], nd[c * 8 + 5], r, best_t,
                                 t1, t2);
-                const uint64_t okm = __ballot(on && (t1 <= t2));
+                const uint64_t okm = onm & mask_le(t1, t2);
                 if (okm != 0) {
                     st.push(sp, child, node * 8u + c, okm);
                     sp++;
@@ -631,13 +644,13 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 const float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
                 const float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
                 const float un = fma_dot(sx, sy, sz, hx, hy, hz);
-                const bool rej_u = surely_negative(un, det);  // u >= 0 cannot hold
-                if (__builtin_amdgcn_ballot_w64(on & !rej_u) == 0) return;
+                const uint64_t rej_u = surely_negative_mask(un, det);  // u >= 0 cannot hold
+                if ((onm & ~rej_u) == 0) return;
                 const float qx = fms(sy, e1z, sz * e1y), qy = fms(sz, e1x, sx * e1z), qz = fms(sx, e1y, sy * e1x);
                 const float vn = fma_dot(r.dx, r.dy, r.dz, qx, qy, qz);
                 const float tn = fma_dot(e2x, e2y, e2z, qx, qy, qz);
-                const bool rej_vt = surely_negative(vn, det) | surely_negative(tn, det);  // v >= 0 / t >= 0 cannot hold
-                if (__builtin_amdgcn_ballot_w64(on & !rej_u & !rej_vt) == 0) return;
+                const uint64_t rej_vt = surely_negative_mask(vn, det) | surely_negative_mask(tn, det);  // v >= 0 / t >= 0 cannot hold
+                if ((onm & ~rej_u & ~rej_vt) == 0) return;
                 const float inv_det = 1.0f / det;
                 const float u = inv_det * un, v = inv_det * vn, t = inv_det * tn;
                 // mask & t>=0 & t<=max_t (:125), strict `<` vs the leaf best, then vs the global best (:129,:59):
