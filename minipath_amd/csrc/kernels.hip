@@ -465,14 +465,16 @@ constexpr float kHuge = 1099511627776.0f;        // 2^40
 
 // Lane masks straight from the compare unit (v_cmp writes the 64-bit mask; no bool -> int -> ballot round trip, which costs two
 // VALU per use): LLVM CmpInst predicate numbers.
-constexpr int kFcmpOGE = 3, kFcmpOLE = 5, kIcmpSLT = 40;
+constexpr int kFcmpOGT = 2, kFcmpOGE = 3, kFcmpOLT = 4, kFcmpOLE = 5;
+__device__ __forceinline__ uint64_t mask_gt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOGT); }
+__device__ __forceinline__ uint64_t mask_lt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOLT); }
 __device__ __forceinline__ uint64_t mask_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOLE); }
 __device__ __forceinline__ uint64_t mask_ge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOGE); }
-__device__ __forceinline__ uint64_t mask_neg(int a) { return __builtin_amdgcn_sicmp(a, 0, kIcmpSLT); }
 
-// surely_negative() as a lane mask
-__device__ __forceinline__ uint64_t surely_negative_mask(float num, float det) {
-    return mask_neg(static_cast<int>(as_u(num) ^ as_u(det))) & mask_ge(fabsf(num), kTiny) & mask_le(fabsf(det), kHuge);
+// surely_negative() as a lane mask.  `det_sign` = sign bit of det, `det_ok` = lanes with |det| <= 2^40: flipping num's sign
+// by det's turns "signs differ and |num| >= 2^-40" into one ordered compare.
+__device__ __forceinline__ uint64_t surely_negative_mask(float num, uint32_t det_sign, uint64_t det_ok) {
+    return det_ok & mask_le(as_f(as_u(num) ^ det_sign), -kTiny);
 }
 
 // True when sign(num) != sign(det) and the quotient fl(fl(1/det) * num) is certainly a non-zero negative number
@@ -603,13 +605,12 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
         uint64_t pm;
         bool is_stale;
         st.pop(sp, link, src, pm, is_stale);
-        bool on = ((pm >> lane) & 1ull) != 0ull;
+        uint64_t onm = pm;  // rays this entry is still live for
         if (is_stale && src != kSrcRoot) {  // :40-44, per ray
             kfp bx = nodes + static_cast<size_t>(src) * 8;
             const float node_t1 = slab_entry<PATCH_NAN>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], r);
-            on = on && !(node_t1 > best_t);
+            onm &= ~mask_gt(node_t1, best_t);
         }
-        const uint64_t onm = __builtin_amdgcn_ballot_w64(on);
         if (onm == 0) continue;
         if ((link & 7u) == 0u) {
             // InnerNode::intersect :149-162, children ascending
@@ -644,23 +645,26 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 const float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
                 const float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
                 const float un = fma_dot(sx, sy, sz, hx, hy, hz);
-                const uint64_t rej_u = surely_negative_mask(un, det);  // u >= 0 cannot hold
+                const uint32_t det_sign = as_u(det) & 0x80000000u;
+                const uint64_t det_ok = mask_le(fabsf(det), kHuge);
+                const uint64_t rej_u = surely_negative_mask(un, det_sign, det_ok);  // u >= 0 cannot hold
                 if ((onm & ~rej_u) == 0) return;
                 const float qx = fms(sy, e1z, sz * e1y), qy = fms(sz, e1x, sx * e1z), qz = fms(sx, e1y, sy * e1x);
                 const float vn = fma_dot(r.dx, r.dy, r.dz, qx, qy, qz);
                 const float tn = fma_dot(e2x, e2y, e2z, qx, qy, qz);
-                const uint64_t rej_vt = surely_negative_mask(vn, det) | surely_negative_mask(tn, det);  // v >= 0 / t >= 0 cannot hold
+                const uint64_t rej_vt = surely_negative_mask(vn, det_sign, det_ok) | surely_negative_mask(tn, det_sign, det_ok);  // v >= 0 / t >= 0 cannot hold
                 if ((onm & ~rej_u & ~rej_vt) == 0) return;
                 const float inv_det = 1.0f / det;
                 const float u = inv_det * un, v = inv_det * vn, t = inv_det * tn;
                 // mask & t>=0 & t<=max_t (:125), strict `<` vs the leaf best, then vs the global best (:129,:59):
                 // equivalent to a running strict `<` against best.t (best.t never exceeds max_t)
-                const bool acc = on & (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) & (t >= 0.0f) & (t < best_t);
+                const uint64_t accm = onm & mask_ge(u, 0.0f) & mask_ge(v, 0.0f) & mask_le(u + v, 1.0f) & mask_ge(t, 0.0f) & mask_lt(t, best_t);
+                const bool acc = __builtin_amdgcn_inverse_ballot_w64(accm);
                 best_t = acc ? t : best_t;
                 bu = acc ? u : bu;
                 bv = acc ? v : bv;
                 bprim = acc ? tri : bprim;
-                changed |= __builtin_amdgcn_ballot_w64(acc);
+                changed |= accm;
             };
             // two register sets (A, B) alternate: B is fetched while A is tested and vice versa (the array has tail padding)
             float a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3], a4 = tp[4], a5 = tp[5], a6 = tp[6], a7 = tp[7], a8 = tp[8];
