@@ -696,8 +696,10 @@ __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, b
 // pixel per pass (lane = pixel*S + sub-sample): all 64 rays of a pass are neighbours on the film, so the packet stays
 // coherent, while the work unit (block x all samples) shrinks with S, which evens out the load.  pixel_sum is
 // accumulated strictly in sample order (worker.rs:41-43) by the lane with sub-sample 0.
-template <int S, bool LDS_STACK>
-__global__ __launch_bounds__(256) void render_tiles_packet_kernel(RenderParams P) {
+// WPE = waves per SIMD the register allocation is held to: 8 (64 VGPRs) hides the scalar-cache misses of scenes that
+// outgrow it, 7 (72 VGPRs) schedules slightly better when the scene stays cache resident (profiles/r01_notes.md).
+template <int S, bool LDS_STACK, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void render_tiles_packet_kernel(RenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : (S <= 32) ? 2 : 1;  // pixel block = BW x BH, BW*BH*S == 64
     constexpr int BH = 64 / S / BW;
@@ -1093,16 +1095,18 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
     const uint32_t per_cu = plds ? std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds)) : 8u;
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want * S, static_cast<uint64_t>(L.cu_count) * per_cu));
-#define MP_LAUNCH_PACKET(SV)                                                                                         \
-    do {                                                                                                             \
-        if (lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<SV, true>), dim3(grid), dim3(256), plds, st, P);  \
-        else hipLaunchKernelGGL((render_tiles_packet_kernel<SV, false>), dim3(grid), dim3(256), 0, st, P);            \
+    // scenes whose traversal arrays exceed the 16 KB scalar data cache by far run 8 waves per SIMD
+    const bool big = (static_cast<uint64_t>(L.scene.inner_count) * 256u + static_cast<uint64_t>(L.scene.packet_count) * 384u) > (1u << 20);
+#define MP_LAUNCH_PACKET(SV, W)                                                                                         \
+    do {                                                                                                                \
+        if (lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<SV, true, W>), dim3(grid), dim3(256), plds, st, P); \
+        else hipLaunchKernelGGL((render_tiles_packet_kernel<SV, false, W>), dim3(grid), dim3(256), 0, st, P);           \
     } while (0)
-    if (S == 2) MP_LAUNCH_PACKET(2);
-    else if (S == 4) MP_LAUNCH_PACKET(4);
-    else if (S == 8) MP_LAUNCH_PACKET(8);
-    else if (S == 16) MP_LAUNCH_PACKET(16);
-    else MP_LAUNCH_PACKET(1);
+    if (S == 8 && big) MP_LAUNCH_PACKET(8, 8);
+    else if (S == 8) MP_LAUNCH_PACKET(8, 7);
+    else if (S == 4) MP_LAUNCH_PACKET(4, 7);
+    else if (S == 2) MP_LAUNCH_PACKET(2, 7);
+    else MP_LAUNCH_PACKET(1, 7);
 #undef MP_LAUNCH_PACKET
     return check(hipGetLastError(), "render_tiles_packet_kernel launch", err);
 }
