@@ -22,7 +22,7 @@ namespace mp {
 namespace {
 
 constexpr uint32_t kNoPrim = 0xFFFFFFFFu;
-constexpr int kQueueFloats = 9 * 64;  // ox,oy,oz,dx,dy,dz,ix,iy,iz x 64 slots ; hit (t,prim,u,v) aliases rows 0..3
+constexpr int kQueueFloats = 6 * 64;  // ox,oy,oz,dx,dy,dz (unit direction) x 64 slots ; hit (t,prim,u,v) aliases rows 0..3
 
 __device__ __forceinline__ float as_f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t as_u(float f) { return __float_as_uint(f); }
@@ -46,11 +46,14 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
     return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, false));
 }
-__device__ __forceinline__ float group_min_f(float v) {
-    v = fminf(v, dpp_f<0x141>(v));
-    v = fminf(v, dpp_f<0xB1>(v));
-    v = fminf(v, dpp_f<0x4E>(v));
-    return v;
+// Minimum of hit distances (>= 0, possibly -0.0, never NaN): on those the signed-integer order of the bit patterns is the float
+// order (-0.0 below +0.0, as v_min_f32 has it), and v_min_i32 takes the DPP operand directly (no canonicalising v_max).
+__device__ __forceinline__ float group_min_t(float v) {
+    int k = __float_as_int(v);
+    k = min(k, __builtin_amdgcn_update_dpp(0, k, 0x141, 0xF, 0xF, false));
+    k = min(k, __builtin_amdgcn_update_dpp(0, k, 0xB1, 0xF, 0xF, false));
+    k = min(k, __builtin_amdgcn_update_dpp(0, k, 0x4E, 0xF, 0xF, false));
+    return __int_as_float(k);
 }
 __device__ __forceinline__ uint32_t group_min_u(uint32_t v) {
     v = min(v, dpp_u<0x141>(v));
@@ -157,7 +160,7 @@ __device__ __forceinline__ float fma_dot(float ax, float ay, float az, float bx,
 // util/simba.rs:61-67 : mul_sub(a, b, c) = a*b - c, c rounded first
 __device__ __forceinline__ float fms(float a, float b, float c) { return __builtin_fmaf(a, b, -c); }
 
-// Traces `nrays` rays held in the wave's LDS queue `q` (rows ox,oy,oz,dx,dy,dz,ix,iy,iz; slot = column).
+// Traces `nrays` rays held in the wave's LDS queue `q` (rows ox,oy,oz,dx,dy,dz; slot = column).
 // On return rows 0..3 of each slot hold the closest hit: t (f32::MAX on miss), prim (bits), u, v.
 // impl Object for TriangleBvh::intersect, ray_bvh_intersection.rs:26-96, for 8 rays at a time.
 __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict__ q, uint2* __restrict__ stack_base,
@@ -172,13 +175,10 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
     int slot = -1, sp = 0, head = 0;
     uint32_t pk = 0, pk_end = 0, seq = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0;
-    // Slab planes by ray sign: with a finite inverse direction, min/max of the two plane distances of an axis is
-    // decided by the sign alone ((bmin-o)*inv <= (bmax-o)*inv for inv > 0 by monotonicity of IEEE rounding, reversed
-    // for inv < 0), and no NaN can arise (0 * finite), so aabb.rs:262-271 reduces to reading the near / far plane
-    // row directly.  Rays with an infinite inverse component (direction component 0 or subnormal) take the literal
-    // path below.
-    int near_x = 0, near_y = 8, near_z = 16, far_x = 24, far_y = 32, far_z = 40;
-    bool slow = false;
+    bool slow = false;  // infinite inverse component: 0 * inf = NaN can arise in the slab test (aabb.rs:262-267)
+    // Lane li fetches child li / triangle li as whole 16-byte words from the AoS copies (two loads per node, three per packet)
+    const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes_aos);
+    const float4* __restrict__ tris4 = reinterpret_cast<const float4*>(sc.tris_aos);
     float best_t = FLT_MAX;                 // best.t, group-uniform (ray_bvh_intersection.rs:34-37)
     float tl = FLT_MAX, ul = 0, vl = 0;     // this lane's earliest closest candidate
     uint32_t pkl = kNoPrim, seql = 0;
@@ -189,7 +189,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
         //    that attains the minimum t.  Every lane kept its own earliest minimum; ties across lanes go to the
         //    smaller (visit sequence, lane).
         if (slot >= 0 && sp == 0 && pk == pk_end) {
-            float tmin = group_min_f(tl);
+            float tmin = group_min_t(tl);
             uint32_t key = (pkl != kNoPrim && tl == tmin) ? ((seql << 3) | static_cast<uint32_t>(li)) : 0xFFFFFFFFu;
             uint32_t kmin = group_min_u(key);
             int wl = src_base | static_cast<int>(kmin & 7u);
@@ -214,10 +214,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
                 slot = mine;
                 ox = q[0 * 64 + mine]; oy = q[1 * 64 + mine]; oz = q[2 * 64 + mine];
                 dx = q[3 * 64 + mine]; dy = q[4 * 64 + mine]; dz = q[5 * 64 + mine];
-                ix = q[6 * 64 + mine]; iy = q[7 * 64 + mine]; iz = q[8 * 64 + mine];
-                near_x = ix < 0.0f ? 24 : 0; far_x = 24 - near_x;
-                near_y = iy < 0.0f ? 32 : 8; far_y = 40 - near_y;
-                near_z = iz < 0.0f ? 40 : 16; far_z = 56 - near_z;
+                // inv_direction as Ray::new has it (geometry/mod.rs:49-53), recomputed rather than queued: 3 LDS rows less per wave
+                ix = (dx == 0.0f) ? INFINITY : 1.0f / dx; iy = (dy == 0.0f) ? INFINITY : 1.0f / dy; iz = (dz == 0.0f) ? INFINITY : 1.0f / dz;
                 slow = fabsf(ix) == INFINITY || fabsf(iy) == INFINITY || fabsf(iz) == INFINITY;
                 best_t = FLT_MAX; tl = FLT_MAX; ul = 0; vl = 0; pkl = kNoPrim; seql = 0; seq = 0;
                 pk = pk_end = 0;
@@ -237,26 +235,18 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
                 if ((link & 7u) == 0u) {
                     // InnerNode::intersect :149-162 ; lane li = child li.  Child boxes are stored decompressed
                     // (SURVEY A.4 box chain evaluated once on the host), so the slab test starts directly.
-                    const float* nd = sc.nodes + static_cast<size_t>(link >> 3) * kNodeDwords + li;
-                    uint32_t child = as_u(nd[48]);
-                    float t1, t2;
-                    if (__ballot(slow) == 0) {
-                        float lox = (nd[near_x] - ox) * ix, loy = (nd[near_y] - oy) * iy, loz = (nd[near_z] - oz) * iz;
-                        float hix = (nd[far_x] - ox) * ix, hiy = (nd[far_y] - oy) * iy, hiz = (nd[far_z] - oz) * iz;
-                        t1 = fmaxf(fmaxf(lox, 0.0f), fmaxf(loy, loz));
-                        t2 = fminf(fminf(hix, best_t), fminf(hiy, hiz));
-                    } else {
-                        // aabb.rs:254-284, literal
-                        float bnx = nd[0], bny = nd[8], bnz = nd[16], bxx = nd[24], bxy = nd[32], bxz = nd[40];
-                        float ax = (bnx - ox) * ix, ay = (bny - oy) * iy, az = (bnz - oz) * iz;
-                        float cx = (bxx - ox) * ix, cy = (bxy - oy) * iy, cz = (bxz - oz) * iz;
+                    const float4* cp = nodes4 + (static_cast<size_t>(link >> 3) * 8 + li) * 2;
+                    const float4 c0 = cp[0], c1 = cp[1];  // {min.xyz, max.x} {max.yz, link, -}
+                    const uint32_t child = as_u(c1.z);
+                    // aabb.rs:254-284
+                    float ax = (c0.x - ox) * ix, ay = (c0.y - oy) * iy, az = (c0.z - oz) * iz;
+                    float cx = (c0.w - ox) * ix, cy = (c1.x - oy) * iy, cz = (c1.y - oz) * iz;
+                    if (__ballot(slow) != 0) {
                         ax = (ax != ax) ? -INFINITY : ax; ay = (ay != ay) ? -INFINITY : ay; az = (az != az) ? -INFINITY : az;
                         cx = (cx != cx) ? INFINITY : cx; cy = (cy != cy) ? INFINITY : cy; cz = (cz != cz) ? INFINITY : cz;
-                        float lox = fminf(ax, cx), loy = fminf(ay, cy), loz = fminf(az, cz);
-                        float hix = fmaxf(ax, cx), hiy = fmaxf(ay, cy), hiz = fmaxf(az, cz);
-                        t1 = fmaxf(fmaxf(lox, 0.0f), fmaxf(loy, loz));
-                        t2 = fminf(fminf(hix, best_t), fminf(hiy, hiz));
                     }
+                    const float t1 = fmaxf(fmaxf(fminf(ax, cx), 0.0f), fmaxf(fminf(ay, cy), fminf(az, cz)));
+                    const float t2 = fminf(fminf(fmaxf(ax, cx), best_t), fminf(fmaxf(ay, cy), fmaxf(az, cz)));
                     bool ok = (t1 <= t2) && (child != MP_LINK_NULL);  // Null links are skipped at pop in the reference (:49)
                     uint32_t m = static_cast<uint32_t>(__ballot(ok) >> (g * 8)) & 0xFFu;
                     if (ok) stack[sp + __popc(m & lanes_below)] = make_uint2(child, as_u(t1));  // ascending lane :161
@@ -269,10 +259,9 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
         }
         // -- B: one leaf packet per iteration (:104-140) ; lane li = triangle li
         if (slot >= 0 && pk < pk_end) {
-            const float* tp = sc.tris + static_cast<size_t>(pk) * kPacketDwords + li;
-            float v0x = tp[0], v0y = tp[8], v0z = tp[16];
-            float e1x = tp[24], e1y = tp[32], e1z = tp[40];
-            float e2x = tp[48], e2y = tp[56], e2z = tp[64];
+            const float4* tp = tris4 + (static_cast<size_t>(pk) * 8 + li) * 3;
+            const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];  // {v0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, -, -, -}
+            const float v0x = q0.x, v0y = q0.y, v0z = q0.z, e1x = q0.w, e1y = q1.x, e1z = q1.y, e2x = q1.z, e2y = q1.w, e2z = q2.x;
             // triangle.rs:183-217
             float hx = fms(dy, e2z, dz * e2y), hy = fms(dz, e2x, dx * e2z), hz = fms(dx, e2y, dy * e2x);
             float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
@@ -286,7 +275,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
             if (valid && t < tl) { tl = t; ul = u; vl = v; pkl = pk; seql = seq; }
             seq++;
             pk++;
-            if (pk == pk_end) best_t = group_min_f(tl);  // `if hit.t < best.t { best = hit }` :59-61
+            if (pk == pk_end) best_t = group_min_t(tl);  // `if hit.t < best.t { best = hit }` :59-61
         }
     }
     wave_lds_sync();
@@ -416,7 +405,6 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
             if (queued) {
                 q[0 * 64 + rank] = r.ox; q[1 * 64 + rank] = r.oy; q[2 * 64 + rank] = r.oz;
                 q[3 * 64 + rank] = r.dx; q[4 * 64 + rank] = r.dy; q[5 * 64 + rank] = r.dz;
-                q[6 * 64 + rank] = r.ix; q[7 * 64 + rank] = r.iy; q[8 * 64 + rank] = r.iz;
             }
             wave_lds_sync();
             trace_wave(P.scene, q, stack, n);
@@ -777,7 +765,7 @@ constexpr float kPathAlbedo = 0.75f;
 constexpr float kPathEps = 1e-4f;
 
 template <int S>
-__global__ __launch_bounds__(256) void render_paths_kernel(RenderParams P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void render_paths_kernel(RenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : 2;
     constexpr int BH = 64 / S / BW;
@@ -836,8 +824,7 @@ __global__ __launch_bounds__(256) void render_paths_kernel(RenderParams P) {
                     if (go) {
                         q[0 * 64 + rank] = r.ox; q[1 * 64 + rank] = r.oy; q[2 * 64 + rank] = r.oz;
                         q[3 * 64 + rank] = r.dx; q[4 * 64 + rank] = r.dy; q[5 * 64 + rank] = r.dz;
-                        q[6 * 64 + rank] = r.ix; q[7 * 64 + rank] = r.iy; q[8 * 64 + rank] = r.iz;
-                    }
+                            }
                     wave_lds_sync();
                     trace_wave(P.scene, q, stack, n);
                     if (go) {
@@ -903,7 +890,7 @@ struct TraceParams {
     uint32_t lds_per_wave;
 };
 
-__global__ __launch_bounds__(256) void trace_rays_kernel(TraceParams P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void trace_rays_kernel(TraceParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
     float* q = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P.lds_per_wave);
@@ -913,10 +900,11 @@ __global__ __launch_bounds__(256) void trace_rays_kernel(TraceParams P) {
     for (uint64_t chunk = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave; chunk < chunks; chunk += stride) {
         const uint64_t i = chunk * 64 + lane;
         const bool act = i < P.n;
-        Ray r;
-        r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
-        if (act) ray_new(P.ox[i], P.oy[i], P.oz[i], P.dx[i], P.dy[i], P.dz[i], r);
-        if (P.scene.kind == 1u) {  // Sphere: HitRecord{t, point, normal, material 0, texture_coords origin} (primitives.rs:40-46)
+        Ray r0;
+        r0.ox = r0.oy = r0.oz = r0.dx = r0.dy = r0.dz = r0.ix = r0.iy = r0.iz = 0.0f;
+        if (act) ray_new(P.ox[i], P.oy[i], P.oz[i], P.dx[i], P.dy[i], P.dz[i], r0);
+        if (P.scene.kind == 1u) {
+            const Ray& r = r0;  // Sphere: HitRecord{t, point, normal, material 0, texture_coords origin} (primitives.rs:40-46)
             if (act) {
                 float t = FLT_MAX, nn[3] = {0, 0, 0};
                 const bool hit = sphere_intersect(P.scene, r, t, nn);
@@ -934,13 +922,12 @@ __global__ __launch_bounds__(256) void trace_rays_kernel(TraceParams P) {
             }
             continue;
         }
-        const bool queued = act && may_hit_scene(P.scene, r);
+        const bool queued = act && may_hit_scene(P.scene, r0);
         const uint64_t am = __ballot(queued);
         const int n = __popcll(am), rank = __popcll(am & ((1ull << lane) - 1ull));
         if (queued) {
-            q[0 * 64 + rank] = r.ox; q[1 * 64 + rank] = r.oy; q[2 * 64 + rank] = r.oz;
-            q[3 * 64 + rank] = r.dx; q[4 * 64 + rank] = r.dy; q[5 * 64 + rank] = r.dz;
-            q[6 * 64 + rank] = r.ix; q[7 * 64 + rank] = r.iy; q[8 * 64 + rank] = r.iz;
+            q[0 * 64 + rank] = r0.ox; q[1 * 64 + rank] = r0.oy; q[2 * 64 + rank] = r0.oz;
+            q[3 * 64 + rank] = r0.dx; q[4 * 64 + rank] = r0.dy; q[5 * 64 + rank] = r0.dz;
         }
         wave_lds_sync();
         trace_wave(P.scene, q, stack, n);
@@ -956,6 +943,8 @@ __global__ __launch_bounds__(256) void trace_rays_kernel(TraceParams P) {
                 float pt[3] = {0, 0, 0}, nn[3] = {0, 0, 0}, tx[3] = {0, 0, 0};
                 if (prim != kNoPrim) {
                     resolve_normal(P.scene, prim, u, v, nn);
+                    Ray r;  // rebuilt here so that no ray registers stay live across the walk
+                    ray_new(P.ox[i], P.oy[i], P.oz[i], P.dx[i], P.dy[i], P.dz[i], r);
                     pt[0] = r.ox + r.dx * t; pt[1] = r.oy + r.dy * t; pt[2] = r.oz + r.dz * t;  // geometry/mod.rs:56-58
                     const uint32_t* vi = P.scene.vidx + static_cast<size_t>(prim) * 3;
                     const float *t0 = P.scene.vtex + 3 * static_cast<size_t>(vi[0]), *t1 = P.scene.vtex + 3 * static_cast<size_t>(vi[1]),
