@@ -111,11 +111,19 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # MP_BENCH_REHEARSAL=1: several ranks share one GPU over gloo (RCCL refuses duplicate devices) -- exercises the N > 1
+    # code path on a one-GPU box; the numbers of such a run mean nothing and the JSON line says so
+    rehearsal = os.environ.get("MP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from minipath_amd.distributed import DistributedFrame
 
@@ -223,7 +231,9 @@ def main():
         achieved = rays_per_launch * b_ray / (k_ms * 1e-3) / 1e9
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        default_workload = (args.scene.endswith("teapot.obj") and (args.width, args.height, args.spp, args.tile) == (1920, 1080, 256, 64)
+                            and args.depth == 0 and args.traversal == "packets")
+        if world == 1 and default_workload and os.path.exists(tp):  # measured for the one-GPU launch of the default workload only
             try:
                 traffic = json.load(open(tp)).get("hbm_bytes_per_launch")
             except Exception:
@@ -240,7 +250,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: ranks share one GPU over gloo; not a measurement)" if rehearsal else ""),
             "samples_per_s": total_samples * args.steps / elapsed,
             "config": {
                 "workload": f"{os.path.basename(args.scene)} {args.width}x{args.height} {args.spp}spp tile{args.tile} "

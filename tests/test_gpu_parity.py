@@ -2,6 +2,7 @@
 on identical seeded inputs.  All comparisons are BIT-EXACT on f32 bit patterns (the north-star tolerance is 1e-5
 relative on the accumulated radiance; the implementation is written to meet it with zero difference) and exact on
 u8 / indices."""
+import os
 import threading
 
 import numpy as np
@@ -578,3 +579,27 @@ def test_sphere_object(ctx, oracle):
     with pytest.raises(mp.MinipathError) as e:  # the build-defined path extension is specified for TriangleBvh only
         mp.render_tile(mp.Scene(sph), cam.build_sampler((128, 128)), mp.RenderSettings(64, 1, (128, 128), max_depth=2), mp.ScreenBlock(0, 0, 64, 64))
     assert e.value.code == 5
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal():
+    """bench.py's N > 1 path (shard plan, gather to rank 0, reassembly, max-over-ranks timing) with two ranks sharing this
+    box's GPU over gloo (MP_BENCH_REHEARSAL=1: RCCL refuses duplicate devices); the gathered frame is checked against the
+    oracle inside bench.py (--check)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MP_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", "320", "--height", "200", "--spp", "16", "--no-cpu-baseline", "--check"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["check_mismatches"] == 0
+    assert d["config"]["rays_per_step"] == 320 * 200 * 16
+    assert d["paths_depth8"]["segments_per_sample"] >= 1.0
