@@ -78,6 +78,8 @@ typedef struct {
     uint64_t seed;
     uint32_t flags;        /* MP_FLAG_* */
     uint32_t max_depth;    /* only with MP_FLAG_PATHS: ray segments per path (>= 1); otherwise ignored (0) */
+    uint32_t pass_begin;   /* only with MP_FLAG_ACCUMULATE: the launch renders samples [pass_begin, pass_begin + pass_count) */
+    uint32_t pass_count;   /*   of sample_count; pass_count 0 = through the last sample.  Otherwise both 0. */
 } mp_settings;
 
 #define MP_FLAG_SHUFFLE_TILES 1u /* centre-out tile order with random noise (screen_block.rs:74-78); default: row-major */
@@ -87,6 +89,14 @@ typedef struct {
  * bounces drawn from the same per-sample Xoshiro stream (UnitDisc rejection + sqrt, Duff et al. basis), origin offset 1e-4
  * along the normal.  rgba = (L, L, L, primary hit ? 1 : 0).  Defined operation by operation in oracle/minipath_oracle.c. */
 #define MP_FLAG_PATHS 4u
+/* Progressive accumulation / checkpoint-resume (SURVEY "aux subsystems"; BASELINE configs[4] is a 65 536-spp progressive
+ * render): with this flag the tile buffer of mp_render_tiles_device[_counted] carries the running per-pixel state of
+ * worker.rs:40-43 between launches -- rgb = the sequential f32 sample sum, a = the hit count.  A launch reads it when
+ * pass_begin > 0, adds its samples in index order, and writes it back; the launch that reaches sample_count writes the means
+ * of worker.rs:44 instead.  Sample s of a pixel is the same ray whichever launch draws it (its stream is keyed by
+ * sample_count and s), so any split of the samples over launches is bit-identical to one launch; the buffer plus the next
+ * pass_begin is the checkpoint (minipath_amd.io.save_checkpoint). */
+#define MP_FLAG_ACCUMULATE 8u
 
 /* machinery.rs:180-189 RenderProgressSnapshot */
 typedef struct { size_t finished, total; } mp_progress;

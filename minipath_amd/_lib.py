@@ -17,6 +17,7 @@ MP_LINK_NULL = 0xFFFFFFF8
 MP_FLAG_SHUFFLE_TILES = 1
 MP_FLAG_TRAVERSAL_GROUPS = 2
 MP_FLAG_PATHS = 4
+MP_FLAG_ACCUMULATE = 8
 
 
 class MinipathError(RuntimeError):
@@ -70,6 +71,8 @@ class SettingsStruct(C.Structure):
         ("seed", C.c_uint64),
         ("flags", C.c_uint32),
         ("max_depth", C.c_uint32),
+        ("pass_begin", C.c_uint32),
+        ("pass_count", C.c_uint32),
     ]
 
 

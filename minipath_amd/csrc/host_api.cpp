@@ -244,8 +244,16 @@ int finish_scene(mp_ctx* ctx, std::unique_ptr<mp_scene> s, mp_scene** out) {
 }
 
 bool valid_settings(const mp_settings* st) {
-    return st && st->tile_size > 0 && st->sample_count > 0 && st->width > 0 && st->height > 0 &&
-           (!(st->flags & MP_FLAG_PATHS) || st->max_depth >= 1);
+    if (!(st && st->tile_size > 0 && st->sample_count > 0 && st->width > 0 && st->height > 0 &&
+          (!(st->flags & MP_FLAG_PATHS) || st->max_depth >= 1)))
+        return false;
+    if (!(st->flags & MP_FLAG_ACCUMULATE)) return st->pass_begin == 0 && st->pass_count == 0;
+    return st->pass_begin < st->sample_count && st->pass_count <= st->sample_count - st->pass_begin;
+}
+// samples per pixel drawn by one launch
+uint32_t pass_samples(const mp_settings& st) {
+    if (!(st.flags & MP_FLAG_ACCUMULATE)) return st.sample_count;
+    return st.pass_count ? st.pass_count : st.sample_count - st.pass_begin;
 }
 
 // Renders `tiles` into a tile-major device buffer (launch only).
@@ -268,6 +276,10 @@ int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_samp
     L.traversal = (st.flags & MP_FLAG_TRAVERSAL_GROUPS) ? 1 : 0;
     L.max_depth = (st.flags & MP_FLAG_PATHS) ? st.max_depth : 0u;
     L.d_segments = reinterpret_cast<unsigned long long*>(d_segments);
+    L.pass_begin = (st.flags & MP_FLAG_ACCUMULATE) ? st.pass_begin : 0u;
+    L.pass_end = L.pass_begin + pass_samples(st);
+    L.carry_in = L.pass_begin > 0;
+    L.finalize = L.pass_end == st.sample_count;
     std::string err;
     int rc = launch_render_tiles(L, stream, err);
     if (rc) return fail(rc, err);
@@ -504,7 +516,7 @@ int mp_render_tiles_device_counted(mp_ctx* ctx, const mp_scene* scene, const mp_
         uint64_t init = 0;
         if (!(settings->flags & MP_FLAG_PATHS))  // reference semantics: one Object::intersect per sample
             for (size_t i = 0; i < n_tiles; i++)
-                init += static_cast<uint64_t>(tiles[i].max_x - tiles[i].min_x) * (tiles[i].max_y - tiles[i].min_y) * settings->sample_count;
+                init += static_cast<uint64_t>(tiles[i].max_x - tiles[i].min_x) * (tiles[i].max_y - tiles[i].min_y) * pass_samples(*settings);
         std::string err;  // the value travels as a kernel argument: no host memory is read after this call returns
         rc = launch_set_u64(reinterpret_cast<unsigned long long*>(d_ray_segments), init, stream, err);
         if (rc) fail(rc, err);
@@ -539,6 +551,7 @@ int mp_untile(mp_ctx* ctx, const mp_settings* settings, const mp_block* tiles, s
 int mp_render_tile(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler, const mp_settings* settings,
                    mp_block tile, float* rgba_f32, uint8_t* rgba_u8) {
     if (!ctx || !scene || !sampler || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
+    if (settings->flags & MP_FLAG_ACCUMULATE) return fail(MP_ERR_INVALID, "MP_FLAG_ACCUMULATE needs a caller-owned device tile buffer: use mp_render_tiles_device");
     if (!(tile.min_x < tile.max_x && tile.min_y < tile.max_y)) return MP_OK;  // empty tile: internal_points yields nothing
     const uint32_t ts = settings->tile_size;
     const uint32_t w = tile.max_x - tile.min_x, h = tile.max_y - tile.min_y;
@@ -666,6 +679,7 @@ extern "C" {
 int mp_render_begin(mp_ctx* ctx, const mp_scene* scene, const mp_camera* camera, const mp_settings* settings,
                     mp_tile_started_cb started, mp_tile_finished_cb finished, void* user, mp_render** out) {
     if (!ctx || !scene || !camera || !out || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
+    if (settings->flags & MP_FLAG_ACCUMULATE) return fail(MP_ERR_INVALID, "render() draws every sample of a tile at once (worker.rs:32-49): MP_FLAG_ACCUMULATE is for mp_render_tiles_device");
     if (scene->ctx != ctx) return fail(MP_ERR_INVALID, "scene belongs to another context");
     auto r = std::make_unique<mp_render>();
     r->ctx = ctx;

@@ -349,10 +349,30 @@ struct RenderParams {
     float* out;           // tile-major RGBA f32
     uint32_t* counter;    // work-queue head
     float inv_spp;        // 1.0 / spp as f32 (worker.rs:44)
+    uint32_t s_begin, s_end;  // samples of this launch (progressive accumulation: a sub-range of [0, spp))
+    uint32_t carry_in;    // out holds the running sums / hit counts of samples [0, s_begin)
+    uint32_t finalize;    // write the means (worker.rs:44); otherwise the running sums
     uint32_t lds_per_wave;
     uint32_t max_depth;   // path extension only
     unsigned long long* segments;  // path extension: ray segments traced (Object::intersect calls), may be null
 };
+
+// worker.rs:40-44 with the running state of a pixel carried across launches (MP_FLAG_ACCUMULATE): rgb = sequential sample sum,
+// a = hit count; the launch that draws the last sample writes the means.  Every lane of the pixel loads the same state.
+__device__ __forceinline__ void pixel_state_load(const RenderParams& P, size_t off, bool inpix, float& acc, float& cnt) {
+    acc = 0.0f;
+    cnt = 0.0f;
+    if (P.carry_in && inpix) {
+        const float4 prev = *reinterpret_cast<const float4*>(P.out + off);
+        acc = prev.x;
+        cnt = prev.w;
+    }
+}
+__device__ __forceinline__ void pixel_state_store(const RenderParams& P, size_t off, float acc, float cnt) {
+    const float m = P.finalize ? acc * P.inv_spp : acc;  // worker.rs:44
+    const float a = P.finalize ? cnt * P.inv_spp : cnt;
+    *reinterpret_cast<float4*>(P.out + off) = make_float4(m, m, m, a);
+}
 
 // S = samples of one pixel in flight in a wavefront (64/S pixels x S consecutive samples per pass).
 template <int S>
@@ -368,7 +388,6 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
     const uint32_t total = P.n_tiles * upt;
     const uint64_t lanes_lt = (1ull << lane) - 1ull;
     const int pix = lane / S, sub = lane % S;
-    const uint32_t spp = P.gen.spp;
 
     for (;;) {
         uint32_t unit = 0;
@@ -381,10 +400,12 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
         const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
         const bool inpix = px < T.max_x && py < T.max_y;
         if (__ballot(inpix) == 0) continue;
-        float acc = 0.0f, cnt = 0.0f;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
-        for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+        const size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
+        float acc, cnt;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
+        pixel_state_load(P, off, inpix, acc, cnt);
+        for (uint32_t s0 = P.s_begin; s0 < P.s_end; s0 += S) {
             const uint32_t s = s0 + static_cast<uint32_t>(sub);
-            const bool act = inpix && s < spp;
+            const bool act = inpix && s < P.s_end;
             Ray r;
             r.dx = r.dy = r.dz = 0.0f;
             if (act) sample_ray(P.gen, px, py, s, r);
@@ -426,12 +447,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
                 cnt += __shfl(h, (lane & ~(S - 1)) + j);
             }
         }
-        if (inpix && sub == 0) {
-            float m = acc * P.inv_spp;  // worker.rs:44
-            float4 o = make_float4(m, m, m, cnt * P.inv_spp);
-            size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
-            *reinterpret_cast<float4*>(P.out + off) = o;
-        }
+        if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
     }
 }
 
@@ -459,18 +475,13 @@ __device__ __forceinline__ uint64_t mask_lt(float a, float b) { return __builtin
 __device__ __forceinline__ uint64_t mask_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOLE); }
 __device__ __forceinline__ uint64_t mask_ge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOGE); }
 
-// surely_negative() as a lane mask.  `det_sign` = sign bit of det, `det_ok` = lanes with |det| <= 2^40: flipping num's sign
-// by det's turns "signs differ and |num| >= 2^-40" into one ordered compare.
+// Lane mask of the rays for which sign(num) != sign(det) and the quotient fl(fl(1/det) * num) is certainly a non-zero negative
+// number (|num| >= 2^-40 and |det| <= 2^40 keep |quotient| >= 2^-80(1-eps): no underflow to -0, which would pass `>= 0`).
+// det = +-0 or subnormal gives an infinite reciprocal whose sign still follows det.  NaN never rejects.
+// `det_sign` = sign bit of det, `det_ok` = lanes with |det| <= 2^40: flipping num's sign by det's turns "signs differ and
+// |num| >= 2^-40" into one ordered compare.
 __device__ __forceinline__ uint64_t surely_negative_mask(float num, uint32_t det_sign, uint64_t det_ok) {
     return det_ok & mask_le(as_f(as_u(num) ^ det_sign), -kTiny);
-}
-
-// True when sign(num) != sign(det) and the quotient fl(fl(1/det) * num) is certainly a non-zero negative number
-// (|num| >= 2^-40 and |det| <= 2^40 keep |quotient| >= 2^-80(1-eps): no underflow to -0, which would pass `>= 0`).
-// det = +-0 or subnormal gives an infinite reciprocal whose sign still follows det.  NaN never rejects.
-__device__ __forceinline__ bool surely_negative(float num, float det) {
-    // bitwise & on purpose: three lane masks ANDed on the scalar unit, no short-circuit control flow
-    return (static_cast<int>(as_u(num) ^ as_u(det)) < 0) & (fabsf(num) >= kTiny) & (fabsf(det) <= kHuge);
 }
 
 template <bool PATCH_NAN>
@@ -577,7 +588,6 @@ struct HybridStack {
 template <int MODE, class Stack>
 __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
     constexpr bool PATCH_NAN = MODE == 2;
-    const int lane = static_cast<int>(threadIdx.x) & 63;
     kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
     kfp tris = (kfp)(uintptr_t)sc.tris_aos;
     kup nvalid = (kup)(uintptr_t)sc.pkt_valid;
@@ -696,7 +706,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1));
     const uint32_t ts = P.tile_size;
     const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
-    const uint32_t spp = P.gen.spp;
     for (;;) {
         uint32_t unit = 0;
         if (lane == 0) unit = atomicAdd(P.counter, 1u);
@@ -708,10 +717,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
         const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
         const bool inpix = px < T.max_x && py < T.max_y;
         if (__ballot(inpix) == 0) continue;
-        float acc = 0.0f, cnt = 0.0f;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
-        for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+        const size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
+        float acc, cnt;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
+        pixel_state_load(P, off, inpix, acc, cnt);
+        for (uint32_t s0 = P.s_begin; s0 < P.s_end; s0 += S) {
             const uint32_t s = s0 + static_cast<uint32_t>(sub);
-            const bool act = inpix && s < spp;
+            const bool act = inpix && s < P.s_end;
             Ray r;
             r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
             if (act) sample_ray(P.gen, px, py, s, r);
@@ -748,11 +759,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                 for (int j = 0; j < S; j++) acc += __shfl(c, (lane & ~(S - 1)) + j);  // misses add +0.0 (exact)
             }
         }
-        if (inpix && sub == 0) {
-            float m = acc * P.inv_spp;  // worker.rs:44
-            size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
-            *reinterpret_cast<float4*>(P.out + off) = make_float4(m, m, m, cnt * P.inv_spp);
-        }
+        if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
     }
 }
 
@@ -777,7 +784,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const uint64_t lanes_lt = (1ull << lane) - 1ull;
     const uint32_t ts = P.tile_size;
     const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
-    const uint32_t spp = P.gen.spp;
     unsigned long long segs = 0;  // wave-uniform
     for (;;) {
         uint32_t unit = 0;
@@ -790,10 +796,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
         const bool inpix = px < T.max_x && py < T.max_y;
         if (__ballot(inpix) == 0) continue;
-        float acc = 0.0f, cnt = 0.0f;
-        for (uint32_t s0 = 0; s0 < spp; s0 += S) {
+        const size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
+        float acc, cnt;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
+        pixel_state_load(P, off, inpix, acc, cnt);
+        for (uint32_t s0 = P.s_begin; s0 < P.s_end; s0 += S) {
             const uint32_t s = s0 + static_cast<uint32_t>(sub);
-            const bool act = inpix && s < spp;
+            const bool act = inpix && s < P.s_end;
             Rng rng;
             rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
             Ray r;
@@ -872,11 +880,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 for (int j = 0; j < S; j++) acc += __shfl(L, (lane & ~(S - 1)) + j);
             }
         }
-        if (inpix && sub == 0) {
-            float m = acc * P.inv_spp;
-            size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
-            *reinterpret_cast<float4*>(P.out + off) = make_float4(m, m, m, cnt * P.inv_spp);
-        }
+        if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
     }
     if (lane == 0 && P.segments && segs) atomicAdd(P.segments, segs);
 }
@@ -1050,6 +1054,10 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     P.out = L.d_out;
     P.counter = L.d_counter;
     P.inv_spp = 1.0f / static_cast<float>(L.spp);
+    P.s_begin = L.pass_begin;
+    P.s_end = L.pass_end;
+    P.carry_in = L.carry_in ? 1u : 0u;
+    P.finalize = L.finalize ? 1u : 0u;
     P.max_depth = L.max_depth;
     P.segments = L.d_segments;
     P.lds_per_wave = lds_bytes_per_wave(L.scene.stack_cap);
@@ -1062,7 +1070,8 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     if (L.max_depth > 0 && L.scene.kind != 0u) { err = "the path extension is defined for TriangleBvh scenes only"; return MP_ERR_UNSUPPORTED; }
     if (L.max_depth > 0) {  // build-defined path extension
         const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / lds));
-        const int S = L.spp >= 8 ? 8 : L.spp >= 4 ? 4 : L.spp >= 2 ? 2 : 1;
+        const uint32_t nspp = L.pass_end - L.pass_begin;  // samples per pixel in this launch
+        const int S = nspp >= 8 ? 8 : nspp >= 4 ? 4 : nspp >= 2 ? 2 : 1;
         const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want * S, static_cast<uint64_t>(L.cu_count) * per_cu));
         if (S == 8) hipLaunchKernelGGL(render_paths_kernel<8>, dim3(grid), dim3(256), lds, st, P);
         else if (S == 4) hipLaunchKernelGGL(render_paths_kernel<4>, dim3(grid), dim3(256), lds, st, P);
@@ -1077,7 +1086,8 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     }
     // samples of one pixel in flight per pass: 8 keeps the 64 rays of a pass within a 4x2 pixel footprint and makes
     // the work units 8x smaller than a whole 8x8 block (measured best on MI355X: profiles/r01_notes.md)
-    int S = L.spp >= 8 ? 8 : L.spp >= 4 ? 4 : L.spp >= 2 ? 2 : 1;
+    const uint32_t nspp = L.pass_end - L.pass_begin;  // samples per pixel in this launch
+    int S = nspp >= 8 ? 8 : nspp >= 4 ? 4 : nspp >= 2 ? 2 : 1;
     const bool lds_stack = L.scene.stack_cap > L.scene.packet_stack_regs;
     P.lds_per_wave = lds_stack ? ((L.scene.stack_cap - L.scene.packet_stack_regs) * 20u + 15u) & ~15u : 0u;
     const uint32_t plds = P.lds_per_wave * 4;

@@ -103,6 +103,10 @@ struct RenderLaunch {
     int traversal;             // 0 = ray packets (coherent camera rays), 1 = 8-lane groups
     uint32_t max_depth;        // 0 = reference semantics (worker.rs:51-66); > 0 = build-defined path extension
     unsigned long long* d_segments;  // optional device counter of traced ray segments (path extension)
+    // progressive accumulation (MP_FLAG_ACCUMULATE): samples [pass_begin, pass_end) of spp; carry_in: d_out holds the running
+    // sums of the earlier passes; finalize: write means (worker.rs:44) instead of sums
+    uint32_t pass_begin = 0, pass_end = 0;
+    bool carry_in = false, finalize = true;
 };
 
 int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err);

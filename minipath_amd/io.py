@@ -57,3 +57,39 @@ def save_pfm(path: str, rgb_f32: np.ndarray) -> None:
     with open(path, "wb") as f:
         f.write(f"PF\n{w} {h}\n-1.0\n".encode())
         f.write(img[::-1].tobytes())  # PFM stores the bottom scanline first
+
+
+# ---- checkpoint / resume of a progressive render (SURVEY "aux subsystems": the reference has none; BASELINE configs[4]) ----
+_CKPT_KEYS = ("tile_size", "sample_count", "width", "height", "seed", "max_depth")
+
+
+def _settings_key(settings) -> np.ndarray:
+    w, h = settings.resolution
+    return np.array([settings.tile_size, settings.sample_count, w, h, int(settings.seed) & 0xFFFFFFFFFFFFFFFF, settings.max_depth],
+                    dtype=np.uint64)
+
+
+def save_checkpoint(path: str, renderer, next_sample: int) -> None:
+    """Dump a FrameRenderer's running per-pixel sums (tile-major f32 RGBA: rgb = sequential sample sum, a = hit count) and the
+    index of the next sample to draw, after render_pass().  Plain .npz (no pickle)."""
+    tiles = np.array([[t.min_x, t.min_y, t.max_x, t.max_y] for t in renderer.tiles], dtype=np.uint32).reshape(-1, 4)
+    np.savez(path, sums=renderer.tile_buf.detach().cpu().numpy(), next_sample=np.uint32(next_sample),
+             settings=_settings_key(renderer.settings), tiles=tiles)
+
+
+def load_checkpoint(path: str, renderer) -> int:
+    """Restore the sums into `renderer.tile_buf` and return the next sample index.  The renderer must have been built for the
+    same settings and tile list (the sample streams are keyed by them)."""
+    import torch
+
+    with np.load(path, allow_pickle=False) as z:
+        if not np.array_equal(z["settings"], _settings_key(renderer.settings)):
+            raise ValueError("checkpoint was written for other settings: " + ", ".join(_CKPT_KEYS))
+        tiles = np.array([[t.min_x, t.min_y, t.max_x, t.max_y] for t in renderer.tiles], dtype=np.uint32).reshape(-1, 4)
+        if not np.array_equal(z["tiles"], tiles):
+            raise ValueError("checkpoint was written for another tile list")
+        sums = z["sums"]
+        if tuple(sums.shape) != tuple(renderer.tile_buf.shape):
+            raise ValueError("checkpoint buffer shape differs")
+        renderer.tile_buf.copy_(torch.from_numpy(np.ascontiguousarray(sums)))
+        return int(z["next_sample"])

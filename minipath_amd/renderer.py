@@ -38,6 +38,8 @@ class RenderSettings:
             | (_lib.MP_FLAG_TRAVERSAL_GROUPS if self.traversal == "groups" else 0)
             | (_lib.MP_FLAG_PATHS if self.max_depth > 0 else 0),
             int(self.max_depth),
+            0,
+            0,
         )
 
 
@@ -195,6 +197,26 @@ class FrameRenderer:
             )
         )
         return self.tile_buf
+
+    def render_pass(self, begin: int, count: int = 0) -> int:
+        """Progressive accumulation (MP_FLAG_ACCUMULATE): draws samples [begin, begin+count) of settings.sample_count
+        (count 0 = through the last) on top of the running per-pixel sums `tile_buf` holds from the earlier passes, and returns
+        the next sample index.  The pass that reaches sample_count leaves the means of worker.rs:44 in `tile_buf`; any split
+        of the samples over passes gives the bit-identical frame of one render().  `tile_buf` + the returned index is the
+        checkpoint (io.save_checkpoint / io.load_checkpoint)."""
+        total = int(self.settings.sample_count)
+        if not (0 <= begin < total) or count < 0 or begin + count > total:
+            raise ValueError("pass outside [0, sample_count)")
+        st = _lib.SettingsStruct.from_buffer_copy(self._st)
+        st.flags |= _lib.MP_FLAG_ACCUMULATE
+        st.pass_begin, st.pass_count = int(begin), int(count)
+        _lib.check(
+            _lib.lib().mp_render_tiles_device_counted(
+                self.ctx.handle, self.scene.object.handle, C.byref(self._sampler), C.byref(st), self._tiles_c,
+                len(self.tiles), self.tile_buf.data_ptr(), self.segments.data_ptr(), self._stream(),
+            )
+        )
+        return total if count == 0 else begin + count
 
     def untile(self, tile_buf=None, tiles: Optional[Sequence[ScreenBlock]] = None, want_u8: bool = True, reuse: bool = False):
         """Tile-major -> image-major f32 (+ u8 via color_to_image) on the device.  Empty blocks in `tiles` (padding of

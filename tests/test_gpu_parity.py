@@ -581,6 +581,60 @@ def test_sphere_object(ctx, oracle):
     assert e.value.code == 5
 
 
+@pytest.mark.parametrize("max_depth,traversal", [(0, "packets"), (0, "groups"), (5, "packets")])
+def test_progressive_passes_equal_single_launch(teapot, tmp_path, max_depth, traversal):
+    """MP_FLAG_ACCUMULATE: the samples of a frame drawn in several launches (ragged pass sizes, not multiples of the 8 samples in
+    flight) accumulate to the bit-identical frame of one launch, also through a checkpoint file and a fresh renderer; the running
+    state between passes is (sum, sum, sum, hit count)."""
+    import torch
+
+    from minipath_amd import io
+
+    cam = mp.Camera.teapot_view()
+    st = mp.RenderSettings(32, 23, (96, 80), seed=SEED, traversal=traversal, max_depth=max_depth)
+    ref = mp.FrameRenderer(teapot, cam, st)
+    ref.render()
+    ref_img, ref_u8 = ref.untile()
+    ref_seg = int(ref.segments.item())
+    prog = mp.FrameRenderer(teapot, cam, st)
+    nxt, seg = 0, 0
+    for count in (1, 7, 9):  # 17 samples, then a checkpoint
+        nxt = prog.render_pass(nxt, count)
+        seg += int(prog.segments.item())
+    assert nxt == 17
+    mid = prog.tile_buf.clone()
+    assert float(mid[..., 3].max()) <= 17.0 and torch.equal(mid[..., 0], mid[..., 1])  # sums and hit counts, not means
+    assert float(mid[..., 3].max()) == 17.0  # some pixel was hit by every sample so far
+    ck = str(tmp_path / "frame.ckpt.npz")
+    io.save_checkpoint(ck, prog, nxt)
+    resumed = mp.FrameRenderer(teapot, cam, st)
+    nxt2 = io.load_checkpoint(ck, resumed)
+    assert nxt2 == 17
+    assert resumed.render_pass(nxt2, 2) == 19
+    seg += int(resumed.segments.item())
+    assert resumed.render_pass(19) == 23  # through the last sample: writes the means
+    seg += int(resumed.segments.item())
+    img, u8 = resumed.untile()
+    torch.cuda.synchronize()
+    assert torch.equal(img.view(torch.int32), ref_img.view(torch.int32)) and torch.equal(u8, ref_u8)
+    assert seg == ref_seg
+    with pytest.raises(ValueError):
+        resumed.render_pass(23)
+    with pytest.raises(ValueError):
+        io.load_checkpoint(ck, mp.FrameRenderer(teapot, cam, mp.RenderSettings(32, 24, (96, 80), seed=SEED, traversal=traversal, max_depth=max_depth)))
+    # the flag is refused where the library owns the tile buffer
+    bad = st.as_struct()
+    bad.flags |= 8
+    from minipath_amd import _lib
+    import ctypes as C
+
+    out = np.zeros((32, 32, 4), np.float32)
+    smp = cam.build_sampler((96, 80)).as_struct()
+    rc = _lib.lib().mp_render_tile(teapot.object.ctx.handle, teapot.object.handle, C.byref(smp), C.byref(bad),
+                                   mp.ScreenBlock(0, 0, 32, 32).as_struct(), out.ctypes.data, None)
+    assert rc != 0
+
+
 @pytest.mark.gpu
 def test_bench_two_rank_rehearsal():
     """bench.py's N > 1 path (shard plan, gather to rank 0, reassembly, max-over-ranks timing) with two ranks sharing this
