@@ -133,6 +133,19 @@ int upload_scene(mp_scene* s) {
             std::memcpy(&so[9], &flat, 4);
         }
     }
+    // the sign-specialised slab test of the packet walk relies on min <= max for every real child box
+    {
+        bool ordered = true;
+        for (size_t n = 0; n < ni && ordered; n++)
+            for (int i = 0; i < 8 && ordered; i++) {
+                uint32_t link;
+                std::memcpy(&link, &nodes[n * kNodeDwords + 48 + i], 4);
+                if (link == MP_LINK_NULL) continue;
+                for (int k = 0; k < 3; k++)
+                    if (!(nodes[n * kNodeDwords + k * 8 + i] <= nodes[n * kNodeDwords + (k + 3) * 8 + i])) ordered = false;
+            }
+        s->dev.boxes_ordered = ordered ? 1u : 0u;
+    }
     // AoS copies for the scalar-unit fetch of the ray-packet traversal (same values, different order)
     std::vector<float> nodes_aos(std::max<size_t>(ni, 1) * 64, 0.0f);
     for (size_t n = 0; n < ni; n++)

@@ -484,7 +484,11 @@ __device__ __forceinline__ uint64_t surely_negative_mask(float num, uint32_t det
     return det_ok & mask_le(as_f(as_u(num) ^ det_sign), -kTiny);
 }
 
-template <bool PATCH_NAN>
+// OCT >= 0: every ray of the wave has a finite inverse direction with the sign pattern OCT (bit 0: x < 0, bit 1: y < 0,
+// bit 2: z < 0) and the box is ordered (min <= max, checked at upload).  IEEE subtraction and multiplication by a constant are
+// monotone, so (bmin - o) * inv <= (bmax - o) * inv for inv > 0 and >= for inv < 0, and no 0 * inf can arise: the min / max of
+// aabb.rs:269-271 select the near / far plane the sign names, and the six min/max drop out of the compiled code.
+template <bool PATCH_NAN, int OCT>
 __device__ __forceinline__ void slab(float bnx, float bny, float bnz, float bxx, float bxy, float bxz, const Ray& r,
                                      float limit, float& t1, float& t2) {
     // aabb.rs:254-284
@@ -494,8 +498,15 @@ __device__ __forceinline__ void slab(float bnx, float bny, float bnz, float bxx,
         ax = (ax != ax) ? -INFINITY : ax; ay = (ay != ay) ? -INFINITY : ay; az = (az != az) ? -INFINITY : az;
         cx = (cx != cx) ? INFINITY : cx; cy = (cy != cy) ? INFINITY : cy; cz = (cz != cz) ? INFINITY : cz;
     }
-    float lox = fminf(ax, cx), loy = fminf(ay, cy), loz = fminf(az, cz);
-    float hix = fmaxf(ax, cx), hiy = fmaxf(ay, cy), hiz = fmaxf(az, cz);
+    float lox, loy, loz, hix, hiy, hiz;
+    if (OCT >= 0) {
+        lox = (OCT & 1) ? cx : ax; hix = (OCT & 1) ? ax : cx;
+        loy = (OCT & 2) ? cy : ay; hiy = (OCT & 2) ? ay : cy;
+        loz = (OCT & 4) ? cz : az; hiz = (OCT & 4) ? az : cz;
+    } else {
+        lox = fminf(ax, cx); loy = fminf(ay, cy); loz = fminf(az, cz);
+        hix = fmaxf(ax, cx); hiy = fmaxf(ay, cy); hiz = fmaxf(az, cz);
+    }
     t1 = fmaxf(fmaxf(lox, 0.0f), fmaxf(loy, loz));
     t2 = fminf(fminf(hix, limit), fminf(hiy, hiz));
 }
@@ -513,10 +524,10 @@ struct PacketHit {
 // mask is the answer; otherwise t1 is recomputed from the child's box (same operations, same bits as at push time).
 constexpr uint32_t kSrcRoot = 0xFFFFFFFFu;
 
-template <bool PATCH_NAN>
+template <bool PATCH_NAN, int OCT>
 __device__ __forceinline__ float slab_entry(float bnx, float bny, float bnz, float bxx, float bxy, float bxz, const Ray& r) {
     float t1, t2;
-    slab<PATCH_NAN>(bnx, bny, bnz, bxx, bxy, bxz, r, FLT_MAX, t1, t2);
+    slab<PATCH_NAN, OCT>(bnx, bny, bnz, bxx, bxy, bxz, r, FLT_MAX, t1, t2);
     return t1;
 }
 
@@ -585,7 +596,7 @@ struct HybridStack {
 // MODE 1: every active ray has finite inverse directions (no 0*inf, so the NaN patches of aabb.rs:262-267 are dead code).
 // MODE 2: literal aabb.rs:254-284.  (A third variant that ordered each child's planes by a wave-uniform ray octant and dropped
 // the min/max was measured and rejected: +13 VGPRs, no gain -- profiles/r01_notes.md.)
-template <int MODE, class Stack>
+template <int MODE, int OCT, class Stack>
 __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
     constexpr bool PATCH_NAN = MODE == 2;
     kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
@@ -606,7 +617,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
         uint64_t onm = pm;  // rays this entry is still live for
         if (is_stale && src != kSrcRoot) {  // :40-44, per ray
             kfp bx = nodes + static_cast<size_t>(src) * 8;
-            const float node_t1 = slab_entry<PATCH_NAN>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], r);
+            const float node_t1 = slab_entry<PATCH_NAN, OCT>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], r);
             onm &= ~mask_gt(node_t1, best_t);
         }
         if (onm == 0) continue;
@@ -619,7 +630,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 const uint32_t child = __builtin_amdgcn_readfirstlane(as_u(nd[c * 8 + 6]));
                 if (child == MP_LINK_NULL) continue;
                 float t1, t2;
-                slab<PATCH_NAN>(nd[c * 8 + 0], nd[c * 8 + 1], nd[c * 8 + 2], nd[c * 8 + 3], nd[c * 8 + 4], nd[c * 8 + 5], r, best_t,
+                slab<PATCH_NAN, OCT>(nd[c * 8 + 0], nd[c * 8 + 1], nd[c * 8 + 2], nd[c * 8 + 3], nd[c * 8 + 4], nd[c * 8 + 5], r, best_t,
                                 t1, t2);
                 const uint64_t okm = onm & mask_le(t1, t2);
                 if (okm != 0) {
@@ -683,11 +694,31 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
     hit.t = best_t; hit.u = bu; hit.v = bv; hit.prim = bprim;
 }
 
-template <class Stack>
+// OCTANTS: also instantiate the eight sign-specialised walks (the production kernels; the rest keep the generic slab).
+template <bool OCTANTS, class Stack>
 __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
     const bool slow = active && (fabsf(r.ix) == INFINITY || fabsf(r.iy) == INFINITY || fabsf(r.iz) == INFINITY);
-    if (__ballot(slow) == 0) trace_packet_impl<1>(sc, r, active, st, hit);
-    else trace_packet_impl<2>(sc, r, active, st, hit);
+    if (__ballot(slow) != 0) {
+        trace_packet_impl<2, -1>(sc, r, active, st, hit);
+        return;
+    }
+    if (OCTANTS && sc.boxes_ordered) {
+        const uint64_t am = __ballot(active);
+        const uint64_t nx = __ballot(active && r.ix < 0.0f), ny = __ballot(active && r.iy < 0.0f), nz = __ballot(active && r.iz < 0.0f);
+        if ((nx == 0 || nx == am) && (ny == 0 || ny == am) && (nz == 0 || nz == am)) {
+            switch ((nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0)) {
+                case 0: trace_packet_impl<1, 0>(sc, r, active, st, hit); return;
+                case 1: trace_packet_impl<1, 1>(sc, r, active, st, hit); return;
+                case 2: trace_packet_impl<1, 2>(sc, r, active, st, hit); return;
+                case 3: trace_packet_impl<1, 3>(sc, r, active, st, hit); return;
+                case 4: trace_packet_impl<1, 4>(sc, r, active, st, hit); return;
+                case 5: trace_packet_impl<1, 5>(sc, r, active, st, hit); return;
+                case 6: trace_packet_impl<1, 6>(sc, r, active, st, hit); return;
+                default: trace_packet_impl<1, 7>(sc, r, active, st, hit); return;
+            }
+        }
+    }
+    trace_packet_impl<1, -1>(sc, r, active, st, hit);
 }
 
 // Fused tile render on ray packets.  A wave owns a block of 64/S pixels and shoots S consecutive samples of each
@@ -733,10 +764,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                 float* lds = reinterpret_cast<float*>(smem + static_cast<size_t>(static_cast<int>(threadIdx.x) >> 6) * P.lds_per_wave);
                 if (LDS_STACK) {
                     HybridStack st(lds, lane, P.scene.stack_cap, P.scene.packet_stack_regs);
-                    trace_packet(P.scene, r, go, st, h);
+                    trace_packet<false>(P.scene, r, go, st, h);
                 } else {
                     RegStack st(lds, lane);
-                    trace_packet(P.scene, r, go, st, h);
+                    trace_packet<(S == 8)>(P.scene, r, go, st, h);
                 }
             }
             float c = 0.0f;
@@ -823,8 +854,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                     if (__ballot(go) != 0) {
                         RegStack rst(nullptr, lane);
                         HybridStack hst(reinterpret_cast<float*>(stack), lane, P.scene.stack_cap, P.scene.packet_stack_regs);
-                        if (P.scene.stack_cap > P.scene.packet_stack_regs) trace_packet(P.scene, r, go, hst, h);
-                        else trace_packet(P.scene, r, go, rst, h);
+                        if (P.scene.stack_cap > P.scene.packet_stack_regs) trace_packet<false>(P.scene, r, go, hst, h);
+                        else trace_packet<false>(P.scene, r, go, rst, h);
                     }
                 } else {
                     const uint64_t gm = __ballot(go);
