@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                         RegStack rst(nullptr, lane);
                         HybridStack hst(reinterpret_cast<float*>(stack), lane, P.scene.stack_cap, P.scene.packet_stack_regs);
                         if (P.scene.stack_cap > P.scene.packet_stack_regs) trace_packet<false>(P.scene, r, go, hst, h);
-                        else trace_packet<false>(P.scene, r, go, rst, h);
+                        else trace_packet<(S == 8)>(P.scene, r, go, rst, h);
                     }
                 } else {
                     const uint64_t gm = __ballot(go);
