@@ -64,8 +64,6 @@ struct mp_scene {
     mp_ctx* ctx = nullptr;
     HostBvh host;
     DevScene dev;
-    void* d_nodes = nullptr;
-    void* d_tris = nullptr;
     void* d_shade = nullptr;
     void* d_vidx = nullptr;
     void* d_vtex = nullptr;
@@ -92,6 +90,7 @@ struct DeviceGuard {
 int upload_scene(mp_scene* s) {
     const HostBvh& h = s->host;
     const size_t ni = h.inner.size(), np = h.packets.size();
+    // host staging in SoA rows (the oracle's traversal-format layout); the device gets the AoS copies built from it below
     std::vector<float> nodes(std::max<size_t>(ni, 1) * kNodeDwords, 0.0f);
     for (size_t n = 0; n < ni; n++) {
         const InnerNodeRef& nd = h.inner[n];
@@ -175,8 +174,6 @@ int upload_scene(mp_scene* s) {
         return MP_OK;
     };
     int rc;
-    if ((rc = up(&s->d_nodes, nodes.data(), nodes.size() * 4))) return rc;
-    if ((rc = up(&s->d_tris, tris.data(), tris.size() * 4))) return rc;
     if ((rc = up(&s->d_shade, shade.data(), shade.size() * 4))) return rc;
     if ((rc = up(&s->d_vidx, vidx.data(), vidx.size() * 4))) return rc;
     if ((rc = up(&s->d_vtex, h.vtex.data(), h.vtex.size() * 4))) return rc;
@@ -186,13 +183,9 @@ int upload_scene(mp_scene* s) {
     MP_HIP(hipMemcpy(s->d_nodes_aos, nodes_aos.data(), nodes_aos.size() * 4, hipMemcpyHostToDevice));
     if (!tris_aos.empty()) MP_HIP(hipMemcpy(s->d_tris_aos, tris_aos.data(), tris_aos.size() * 4, hipMemcpyHostToDevice));
     if (!pkt_valid.empty()) MP_HIP(hipMemcpy(s->d_pkt_valid, pkt_valid.data(), pkt_valid.size() * 4, hipMemcpyHostToDevice));
-    MP_HIP(hipMemcpy(s->d_nodes, nodes.data(), nodes.size() * 4, hipMemcpyHostToDevice));
-    if (!tris.empty()) MP_HIP(hipMemcpy(s->d_tris, tris.data(), tris.size() * 4, hipMemcpyHostToDevice));
     if (!shade.empty()) MP_HIP(hipMemcpy(s->d_shade, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
     if (!vidx.empty()) MP_HIP(hipMemcpy(s->d_vidx, vidx.data(), vidx.size() * 4, hipMemcpyHostToDevice));
     if (!h.vtex.empty()) MP_HIP(hipMemcpy(s->d_vtex, h.vtex.data(), h.vtex.size() * 4, hipMemcpyHostToDevice));
-    s->dev.nodes = static_cast<const float*>(s->d_nodes);
-    s->dev.tris = static_cast<const float*>(s->d_tris);
     s->dev.shade = static_cast<const float*>(s->d_shade);
     s->dev.vidx = static_cast<const uint32_t*>(s->d_vidx);
     s->dev.vtex = static_cast<const float*>(s->d_vtex);
@@ -435,7 +428,7 @@ void mp_scene_destroy(mp_scene* s) {
     if (!s) return;
     if (s->ctx) {
         DeviceGuard g(s->ctx->device);
-        for (void* p : {s->d_nodes, s->d_tris, s->d_shade, s->d_vidx, s->d_vtex, s->d_nodes_aos, s->d_tris_aos, s->d_pkt_valid})
+        for (void* p : {s->d_shade, s->d_vidx, s->d_vtex, s->d_nodes_aos, s->d_tris_aos, s->d_pkt_valid})
             if (p) (void)hipFree(p);
     }
     delete s;

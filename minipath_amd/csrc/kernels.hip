@@ -306,8 +306,8 @@ __device__ __forceinline__ void resolve_normal(const DevScene& sc, uint32_t prim
     float nx, ny, nz;
     if (as_u(c.y) != 0u) {
         // flat: Triangle::normal (triangle.rs:141-144), unfused cross of the decompressed edges
-        const float* tp = sc.tris + static_cast<size_t>(prim >> 3) * kPacketDwords + (prim & 7u);
-        float e1x = tp[24], e1y = tp[32], e1z = tp[40], e2x = tp[48], e2y = tp[56], e2z = tp[64];
+        const float* tp = sc.tris_aos + static_cast<size_t>(prim) * 12;
+        float e1x = tp[3], e1y = tp[4], e1z = tp[5], e2x = tp[6], e2y = tp[7], e2z = tp[8];
         nx = e1y * e2z - e1z * e2y;
         ny = e1z * e2x - e1x * e2z;
         nz = e1x * e2y - e1y * e2x;

@@ -55,22 +55,19 @@ int load_obj(const char* path, std::vector<float>& pos, std::vector<float>& nrm,
              std::vector<uint32_t>& tri, std::string& err);
 
 // ---- device scene ("traversal format") -------------------------------------------------------
-// nodes : inner_count x 56 dwords : rows minx,miny,minz,maxx,maxy,maxz (f32[8] each, absolute decompressed child
-//         boxes) followed by link[8] (u32).  224 B per node.
-// tris  : packet_count x 72 dwords : rows v0x,v0y,v0z,e1x,e1y,e1z,e2x,e2y,e2z (f32[8] each): decompressed v0 and
-//         the edges e1=v1-v0, e2=v2-v0 of triangle.rs:195-196.  288 B per packet.
-// shade : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) pad pad.  48 B per triangle slot.
+// nodes_aos : inner_count x 8 children x 8 dwords {minx,miny,minz,maxx,maxy,maxz,link,0}: absolute decompressed child boxes.
+// tris_aos  : packet_count x 8 triangles x 12 dwords {v0.xyz,e1.xyz,e2.xyz,0,0,0}: decompressed v0 and the edges e1=v1-v0,
+//             e2=v2-v0 of triangle.rs:195-196 (+ 36 dwords of tail padding: the packet walk fetches two triangles ahead).
+//             The packet walk reads both through the scalar unit (wave-uniform), the 8-lane-group walk as one 16-byte word per
+//             lane (lane i = child i / triangle i).
+// pkt_valid : real (unpadded) triangles of each packet.
+// shade     : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) pad pad.  48 B per triangle slot.
 // vidx/vtex : for the full HitRecord (texture_coords).
 struct DevScene {
     uint32_t kind = 0;               // 0 = TriangleBvh, 1 = Sphere (scene/primitives.rs:10-13)
     float sphere_center[3] = {0, 0, 0};
     float sphere_radius = 0;
-    const float* nodes = nullptr;
-    const float* tris = nullptr;
     const float* shade = nullptr;
-    // AoS copies of the same values for wave-uniform (scalar-unit) fetch by the ray-packet traversal:
-    // nodes_aos: inner x 8 children x 8 dwords {minx,miny,minz,maxx,maxy,maxz,link,0} ; tris_aos: packets x 8 x 12
-    // dwords {v0.xyz,e1.xyz,e2.xyz,0,0,0} ; pkt_valid: real (unpadded) triangles of each packet
     const float* nodes_aos = nullptr;
     const float* tris_aos = nullptr;
     const uint32_t* pkt_valid = nullptr;
@@ -87,8 +84,8 @@ struct DevScene {
     float pre_min[3] = {0, 0, 0}, pre_max[3] = {0, 0, 0};
 };
 
-constexpr int kNodeDwords = 56;
-constexpr int kPacketDwords = 72;
+constexpr int kNodeDwords = 56;    // host staging rows: minx..maxz (8 floats each) + link[8]
+constexpr int kPacketDwords = 72;  // host staging rows: v0.xyz, e1.xyz, e2.xyz (8 floats each)
 
 // ---- kernel launchers (kernels.hip) ---------------------------------------------------------------------
 struct RenderLaunch {
