@@ -197,6 +197,20 @@ int mp_render_tiles_device(mp_ctx *ctx, const mp_scene *scene, const mp_camera_s
 int mp_render_tiles_device_counted(mp_ctx *ctx, const mp_scene *scene, const mp_camera_sampler *sampler,
                                    const mp_settings *settings, const mp_block *tiles, size_t n_tiles, float *d_rgba_f32,
                                    uint64_t *d_ray_segments, void *stream);
+/* Same, with optional extras (any member may be NULL).  The waves of a launch take tiles from one queue, like the reference's
+ * workers (machinery.rs:206-208 get_next_tile), in the order of the `tiles` array -- or, with `tile_order` (host, a permutation
+ * of 0..n_tiles-1), in that order while tile i still renders to slot i.  `d_tile_cost` (device u64[n_tiles]) is incremented by the
+ * shader-clock cycles the waves spent on each tile: handing out the expensive tiles first (order = argsort of the previous
+ * frame's or progressive pass's cost, descending) shortens the tail of a launch, most of all for the small per-rank launches of a
+ * multi-GPU frame.  Results do not depend on the order. */
+typedef struct {
+    uint64_t *d_ray_segments;   /* as in mp_render_tiles_device_counted */
+    uint64_t *d_tile_cost;      /* device u64[n_tiles], accumulated (+=) */
+    const uint32_t *tile_order; /* host u32[n_tiles] */
+} mp_launch_extras;
+int mp_render_tiles_device_ex(mp_ctx *ctx, const mp_scene *scene, const mp_camera_sampler *sampler,
+                              const mp_settings *settings, const mp_block *tiles, size_t n_tiles, float *d_rgba_f32,
+                              const mp_launch_extras *extras, void *stream);
 /* machinery.rs:78-89 (tile buffer -> image copy) on the device: scatters tile-major tiles into an image-major
  * f32 frame and/or its color_to_image u8 frame (either may be NULL). */
 int mp_untile(mp_ctx *ctx, const mp_settings *settings, const mp_block *tiles, size_t n_tiles,

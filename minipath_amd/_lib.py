@@ -107,6 +107,10 @@ class HitsSoA(C.Structure):
     ]
 
 
+class LaunchExtras(C.Structure):
+    _fields_ = [("d_ray_segments", C.c_void_p), ("d_tile_cost", C.c_void_p), ("tile_order", C.POINTER(C.c_uint32))]
+
+
 STARTED_CB = C.CFUNCTYPE(None, C.c_void_p, Block)
 FINISHED_CB = C.CFUNCTYPE(None, C.c_void_p, Block, Progress)
 
@@ -153,6 +157,11 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.POINTER(SamplerStruct), C.POINTER(SettingsStruct), C.POINTER(Block), C.c_size_t,
          C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "mp_render_tiles_device_ex": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.POINTER(SamplerStruct), C.POINTER(SettingsStruct), C.POINTER(Block), C.c_size_t,
+         C.c_void_p, C.POINTER(LaunchExtras), C.c_void_p],
     ),
     "mp_untile": (
         C.c_int,

@@ -57,6 +57,7 @@ struct mp_ctx {
     uint32_t* d_counters = nullptr;
     std::atomic<uint32_t> next_counter{0};
     std::atomic<uint32_t> packet_stack_regs{64};
+    std::atomic<uint32_t> packet_samples{0};  // 0 = chosen by the launcher
     uint32_t* take_counter() { return d_counters + (next_counter.fetch_add(1, std::memory_order_relaxed) % kCounters); }
 };
 
@@ -264,10 +265,12 @@ uint32_t pass_samples(const mp_settings& st) {
 
 // Renders `tiles` into a tile-major device buffer (launch only).
 int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler& sampler, const mp_settings& st,
-                        const mp_block* d_tiles, size_t n, float* d_out, void* stream, uint64_t* d_segments = nullptr) {
+                        const mp_block* d_tiles, size_t n, float* d_out, void* stream, uint64_t* d_segments = nullptr,
+                        const uint32_t* d_tile_order = nullptr, uint64_t* d_tile_cost = nullptr) {
     RenderLaunch L;
     L.scene = scene->dev;
     L.scene.packet_stack_regs = ctx->packet_stack_regs.load();
+    L.packet_samples = ctx->packet_samples.load();
     L.sampler = sampler;
     L.width = st.width;
     L.height = st.height;
@@ -282,6 +285,8 @@ int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_samp
     L.traversal = (st.flags & MP_FLAG_TRAVERSAL_GROUPS) ? 1 : 0;
     L.max_depth = (st.flags & MP_FLAG_PATHS) ? st.max_depth : 0u;
     L.d_segments = reinterpret_cast<unsigned long long*>(d_segments);
+    L.d_tile_order = d_tile_order;
+    L.d_tile_cost = reinterpret_cast<unsigned long long*>(d_tile_cost);
     L.pass_begin = (st.flags & MP_FLAG_ACCUMULATE) ? st.pass_begin : 0u;
     L.pass_end = L.pass_begin + pass_samples(st);
     L.carry_in = L.pass_begin > 0;
@@ -329,6 +334,12 @@ int mp_ctx_set_option(mp_ctx* ctx, const char* key, int value) {
     if (std::strcmp(key, "packet_stack_registers") == 0) {
         if (value < 1 || value > 64) return fail(MP_ERR_INVALID, "packet_stack_registers must be in 1..64");
         ctx->packet_stack_regs.store(static_cast<uint32_t>(value));
+        return MP_OK;
+    }
+    if (std::strcmp(key, "packet_samples_in_flight") == 0) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64)
+            return fail(MP_ERR_INVALID, "packet_samples_in_flight must be 0 (automatic) or a power of two up to 64");
+        ctx->packet_samples.store(static_cast<uint32_t>(value));
         return MP_OK;
     }
     return fail(MP_ERR_INVALID, std::string("unknown option: ") + key);
@@ -501,21 +512,44 @@ int mp_render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_s
 int mp_render_tiles_device_counted(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler,
                                    const mp_settings* settings, const mp_block* tiles, size_t n_tiles, float* d_rgba_f32,
                                    uint64_t* d_ray_segments, void* stream) {
+    mp_launch_extras ex{d_ray_segments, nullptr, nullptr};
+    return mp_render_tiles_device_ex(ctx, scene, sampler, settings, tiles, n_tiles, d_rgba_f32, &ex, stream);
+}
+
+int mp_render_tiles_device_ex(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler, const mp_settings* settings,
+                              const mp_block* tiles, size_t n_tiles, float* d_rgba_f32, const mp_launch_extras* extras,
+                              void* stream) {
     if (!ctx || !scene || !sampler || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
     if (n_tiles && (!tiles || !d_rgba_f32)) return fail(MP_ERR_INVALID, "NULL tiles/output");
     if (scene->ctx != ctx) return fail(MP_ERR_INVALID, "scene belongs to another context");
     if (n_tiles == 0) return MP_OK;
+    if (n_tiles > 0xFFFFFFFFull) return fail(MP_ERR_INVALID, "too many tiles");
+    uint64_t* d_ray_segments = extras ? extras->d_ray_segments : nullptr;
+    uint64_t* d_tile_cost = extras ? extras->d_tile_cost : nullptr;
+    const uint32_t* tile_order = extras ? extras->tile_order : nullptr;
     for (size_t i = 0; i < n_tiles; i++) {
         const mp_block& t = tiles[i];
         if (!(t.min_x < t.max_x && t.min_y < t.max_y) || t.max_x - t.min_x > settings->tile_size ||
             t.max_y - t.min_y > settings->tile_size || t.max_x > settings->width || t.max_y > settings->height)
             return fail(MP_ERR_INVALID, "tile empty, larger than tile_size, or outside the resolution");
     }
+    if (tile_order) {  // must be a permutation: every tile is rendered exactly once
+        std::vector<bool> seen(n_tiles, false);
+        for (size_t i = 0; i < n_tiles; i++) {
+            if (tile_order[i] >= n_tiles || seen[tile_order[i]]) return fail(MP_ERR_INVALID, "tile_order is not a permutation of 0..n_tiles-1");
+            seen[tile_order[i]] = true;
+        }
+    }
     DeviceGuard g(ctx->device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    mp_block* d_tiles = nullptr;
-    MP_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_tiles), n_tiles * sizeof(mp_block), st));
-    hipError_t e = hipMemcpyAsync(d_tiles, tiles, n_tiles * sizeof(mp_block), hipMemcpyHostToDevice, st);
+    // one staging buffer: the tile list, then (optionally) the hand-out order
+    const size_t tiles_bytes = n_tiles * sizeof(mp_block), order_bytes = tile_order ? n_tiles * sizeof(uint32_t) : 0;
+    unsigned char* d_stage = nullptr;
+    MP_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_stage), tiles_bytes + order_bytes, st));
+    mp_block* d_tiles = reinterpret_cast<mp_block*>(d_stage);
+    uint32_t* d_order = tile_order ? reinterpret_cast<uint32_t*>(d_stage + tiles_bytes) : nullptr;
+    hipError_t e = hipMemcpyAsync(d_tiles, tiles, tiles_bytes, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess && tile_order) e = hipMemcpyAsync(d_order, tile_order, order_bytes, hipMemcpyHostToDevice, st);
     int rc = MP_OK;
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(tiles)");
     if (!rc && d_ray_segments) {
@@ -527,8 +561,8 @@ int mp_render_tiles_device_counted(mp_ctx* ctx, const mp_scene* scene, const mp_
         rc = launch_set_u64(reinterpret_cast<unsigned long long*>(d_ray_segments), init, stream, err);
         if (rc) fail(rc, err);
     }
-    if (!rc) rc = render_tiles_device(ctx, scene, *sampler, *settings, d_tiles, n_tiles, d_rgba_f32, stream, d_ray_segments);
-    (void)hipFreeAsync(d_tiles, st);
+    if (!rc) rc = render_tiles_device(ctx, scene, *sampler, *settings, d_tiles, n_tiles, d_rgba_f32, stream, d_ray_segments, d_order, d_tile_cost);
+    (void)hipFreeAsync(d_stage, st);
     return rc;
 }
 

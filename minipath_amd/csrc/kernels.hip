@@ -352,6 +352,8 @@ struct RenderParams {
     uint32_t s_begin, s_end;  // samples of this launch (progressive accumulation: a sub-range of [0, spp))
     uint32_t carry_in;    // out holds the running sums / hit counts of samples [0, s_begin)
     uint32_t finalize;    // write the means (worker.rs:44); otherwise the running sums
+    const uint32_t* tile_order;      // optional hand-out order: work slot k renders tile tile_order[k] (into that tile's own slot)
+    unsigned long long* tile_cost;   // optional: += shader-clock cycles the waves spent on each tile
     uint32_t lds_per_wave;
     uint32_t max_depth;   // path extension only
     unsigned long long* segments;  // path extension: ray segments traced (Object::intersect calls), may be null
@@ -394,7 +396,9 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
         if (lane == 0) unit = atomicAdd(P.counter, 1u);
         unit = __builtin_amdgcn_readfirstlane(unit);
         if (unit >= total) break;
-        const uint32_t tile_i = unit / upt, b = unit % upt;
+        const uint32_t b = unit % upt;
+        const uint32_t tile_i = P.tile_order ? P.tile_order[unit / upt] : unit / upt;
+        const uint64_t t_unit = P.tile_cost ? __builtin_readcyclecounter() : 0;
         const mp_block T = P.tiles[tile_i];
         const uint32_t px = T.min_x + (b % bx) * BW + static_cast<uint32_t>(pix % BW);
         const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
@@ -448,6 +452,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
             }
         }
         if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
+        if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
     }
 }
 
@@ -721,6 +726,32 @@ __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, b
     trace_packet_impl<1, -1>(sc, r, active, st, hit);
 }
 
+// pixel_sum += sample, strictly in sample order (worker.rs:41-43), for the S samples of a pixel held by S consecutive lanes.
+// S = 16 is one DPP row: v_add_f32_dpp with row_newbcast:j adds lane j of the row in ONE instruction (no LDS permute); every
+// lane of the row ends with the same sum.  Inactive samples contribute +0.0 (exact).
+template <int J, int N>
+struct RowSum {
+    static __device__ __forceinline__ void run(float& acc, float c) {
+        acc += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(c), 0x150 + J, 0xF, 0xF, false));
+        RowSum<J + 1, N>::run(acc, c);
+    }
+};
+template <int N>
+struct RowSum<N, N> {
+    static __device__ __forceinline__ void run(float&, float) {}
+};
+template <int S>
+__device__ __forceinline__ void add_samples_in_order(float& acc, float c, int lane) {
+    if (S == 1) {
+        acc += c;
+    } else if (S == 16) {
+        RowSum<0, 16>::run(acc, c);
+    } else {
+#pragma unroll
+        for (int j = 0; j < S; j++) acc += __shfl(c, (lane & ~(S - 1)) + j);
+    }
+}
+
 // Fused tile render on ray packets.  A wave owns a block of 64/S pixels and shoots S consecutive samples of each
 // pixel per pass (lane = pixel*S + sub-sample): all 64 rays of a pass are neighbours on the film, so the packet stays
 // coherent, while the work unit (block x all samples) shrinks with S, which evens out the load.  pixel_sum is
@@ -742,7 +773,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
         if (lane == 0) unit = atomicAdd(P.counter, 1u);
         unit = __builtin_amdgcn_readfirstlane(unit);
         if (unit >= total) break;
-        const uint32_t tile_i = unit / upt, b = unit % upt;
+        const uint32_t b = unit % upt;
+        const uint32_t tile_i = P.tile_order ? P.tile_order[unit / upt] : unit / upt;
+        const uint64_t t_unit = P.tile_cost ? __builtin_readcyclecounter() : 0;
         const mp_block T = P.tiles[tile_i];
         const uint32_t px = T.min_x + (b % bx) * BW + static_cast<uint32_t>(pix % BW);
         const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
@@ -767,7 +800,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                     trace_packet<false>(P.scene, r, go, st, h);
                 } else {
                     RegStack st(lds, lane);
-                    trace_packet<(S == 8)>(P.scene, r, go, st, h);
+                    trace_packet<(S >= 8 && S <= 32)>(P.scene, r, go, st, h);
                 }
             }
             float c = 0.0f;
@@ -783,14 +816,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
             }
             // alpha sums 1.0 per hit: an exact integer in f32, so the order is irrelevant
             cnt += static_cast<float>(__popcll(__ballot(hit) & pixel_lanes));
-            if (S == 1) {
-                acc += c;
-            } else {
-#pragma unroll
-                for (int j = 0; j < S; j++) acc += __shfl(c, (lane & ~(S - 1)) + j);  // misses add +0.0 (exact)
-            }
+            add_samples_in_order<S>(acc, c, lane);  // misses add +0.0 (exact)
         }
         if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
+        if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
     }
 }
 
@@ -821,7 +850,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         if (lane == 0) unit = atomicAdd(P.counter, 1u);
         unit = __builtin_amdgcn_readfirstlane(unit);
         if (unit >= total) break;
-        const uint32_t tile_i = unit / upt, b = unit % upt;
+        const uint32_t b = unit % upt;
+        const uint32_t tile_i = P.tile_order ? P.tile_order[unit / upt] : unit / upt;
+        const uint64_t t_unit = P.tile_cost ? __builtin_readcyclecounter() : 0;
         const mp_block T = P.tiles[tile_i];
         const uint32_t px = T.min_x + (b % bx) * BW + static_cast<uint32_t>(pix % BW);
         const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
@@ -912,6 +943,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             }
         }
         if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
+        if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
     }
     if (lane == 0 && P.segments && segs) atomicAdd(P.segments, segs);
 }
@@ -1089,6 +1121,8 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     P.s_end = L.pass_end;
     P.carry_in = L.carry_in ? 1u : 0u;
     P.finalize = L.finalize ? 1u : 0u;
+    P.tile_order = L.d_tile_order;
+    P.tile_cost = L.d_tile_cost;
     P.max_depth = L.max_depth;
     P.segments = L.d_segments;
     P.lds_per_wave = lds_bytes_per_wave(L.scene.stack_cap);
@@ -1118,7 +1152,8 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     // samples of one pixel in flight per pass: 8 keeps the 64 rays of a pass within a 4x2 pixel footprint and makes
     // the work units 8x smaller than a whole 8x8 block (measured best on MI355X: profiles/r01_notes.md)
     const uint32_t nspp = L.pass_end - L.pass_begin;  // samples per pixel in this launch
-    int S = nspp >= 8 ? 8 : nspp >= 4 ? 4 : nspp >= 2 ? 2 : 1;
+    int S = nspp >= 16 ? 16 : nspp >= 8 ? 8 : nspp >= 4 ? 4 : nspp >= 2 ? 2 : 1;
+    if (L.packet_samples) S = static_cast<int>(std::min<uint32_t>(L.packet_samples, 64u));
     const bool lds_stack = L.scene.stack_cap > L.scene.packet_stack_regs;
     P.lds_per_wave = lds_stack ? ((L.scene.stack_cap - L.scene.packet_stack_regs) * 20u + 15u) & ~15u : 0u;
     const uint32_t plds = P.lds_per_wave * 4;
@@ -1132,7 +1167,10 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         if (lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<SV, true, W>), dim3(grid), dim3(256), plds, st, P); \
         else hipLaunchKernelGGL((render_tiles_packet_kernel<SV, false, W>), dim3(grid), dim3(256), 0, st, P);           \
     } while (0)
-    if (S == 8 && big) MP_LAUNCH_PACKET(8, 8);
+    if (S == 64) MP_LAUNCH_PACKET(64, 7);
+    else if (S == 32) MP_LAUNCH_PACKET(32, 7);
+    else if (S == 16 && big) MP_LAUNCH_PACKET(16, 8);
+    else if (S == 16) MP_LAUNCH_PACKET(16, 7);
     else if (S == 8) MP_LAUNCH_PACKET(8, 7);
     else if (S == 4) MP_LAUNCH_PACKET(4, 7);
     else if (S == 2) MP_LAUNCH_PACKET(2, 7);

@@ -105,6 +105,9 @@ struct RenderLaunch {
     // sums of the earlier passes; finalize: write means (worker.rs:44) instead of sums
     uint32_t pass_begin = 0, pass_end = 0;
     bool carry_in = false, finalize = true;
+    uint32_t packet_samples = 0;  // samples of a pixel in flight per pass of the packet kernel (0 = automatic)
+    const uint32_t* d_tile_order = nullptr;      // optional: hand-out order of the tiles (device, n_tiles)
+    unsigned long long* d_tile_cost = nullptr;   // optional: += shader-clock cycles spent per tile (device, n_tiles)
 };
 
 int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err);

@@ -62,7 +62,11 @@ def gather_shards(shard, plan: ShardPlan, rank: int, group=None, dst: int = 0):
 class DistributedFrame:
     """Per-rank driver used by bench.py: render my shard in one launch straight into the gather source buffer, gather
     into one preallocated rank-major buffer on rank 0, un-tile there (padding slots are empty blocks the kernel skips).
-    Nothing is allocated per frame."""
+    Nothing is allocated per frame.
+
+    With more than one rank the frames are pipelined one deep: the gather of frame k runs on RCCL's stream while the compute
+    stream already renders frame k+1 into the second shard buffer, so the xGMI transfer is off the critical path.  step()
+    therefore returns the image of the PREVIOUS frame (None for the first one); flush() completes the last frame."""
 
     def __init__(self, scene, camera, settings, rank: int, world: int, tiles: Optional[Sequence[ScreenBlock]] = None):
         import torch
@@ -77,9 +81,12 @@ class DistributedFrame:
         self.plan = plan_shards(self.all_tiles, world)
         ts = settings.tile_size
         dev = torch.device("cuda", scene.object.ctx.device_id)
-        self.shard = torch.zeros((max(self.plan.per_rank, 1), ts, ts, 4), dtype=torch.float32, device=dev)
-        self.renderer = FrameRenderer(scene, camera, settings, tiles=self.plan.shards[rank], tile_buf=self.shard)
+        nbuf = 2 if world > 1 else 1
+        self._shards = [torch.zeros((max(self.plan.per_rank, 1), ts, ts, 4), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+        self.renderer = FrameRenderer(scene, camera, settings, tiles=self.plan.shards[rank], tile_buf=self._shards[0])
         self._gather_buf = self._gather_views = self._order = None
+        self._pending = None   # (work, want_u8) of the gather in flight
+        self._frame = 0
         if rank == 0 and world > 1:
             self._gather_buf = torch.zeros((world * self.plan.per_rank, ts, ts, 4), dtype=torch.float32, device=dev)
             self._gather_views = [self._gather_buf[r * self.plan.per_rank:(r + 1) * self.plan.per_rank] for r in range(world)]
@@ -87,25 +94,54 @@ class DistributedFrame:
             self._order = (order, (_lib.Block * max(len(order), 1))(*[t.as_struct() for t in order]))
 
     @property
+    def shard(self):
+        """The shard buffer the next render writes."""
+        return self._shards[self._frame % len(self._shards)]
+
+    @property
     def rays_per_frame_local(self) -> int:
         return self.renderer.rays_per_frame
 
     def render_local(self):
+        self.renderer.tile_buf = self.shard
         return self.renderer.render()
 
+    def rebalance(self):
+        """Profile-guided tile hand-out for this rank's following launches (FrameRenderer.rebalance): purely local, the shard
+        layout and the gather do not change."""
+        return self.renderer.rebalance()
+
+    def _complete(self):
+        """Wait (on the current stream) for the gather in flight and un-tile its frame on rank 0."""
+        if self._pending is None:
+            return None, None
+        work, want_u8 = self._pending
+        self._pending = None
+        work.wait()
+        if self.rank != 0:
+            return None, None
+        return self.renderer.untile(self._gather_buf, self._order, want_u8=want_u8, reuse=True)
+
     def step(self, want_u8: bool = True, kernel_events=None):
-        """One frame: returns (image f32, image u8) on rank 0, (None, None) elsewhere.  kernel_events = (start, end)
-        torch.cuda.Event pair recorded around the render launch on the current stream."""
+        """One frame.  world == 1: returns (image f32, image u8) of this frame.  world > 1: launches this frame's render,
+        completes the PREVIOUS frame (gather wait + un-tile; returns its images on rank 0, (None, None) elsewhere and for
+        the first frame), then starts this frame's gather.  kernel_events = (start, end) torch.cuda.Event pair recorded around
+        the render launch on the current stream."""
         import torch.distributed as dist
 
         if kernel_events is not None:
             kernel_events[0].record()
-        self.render_local()
+        src = self.render_local()
         if kernel_events is not None:
             kernel_events[1].record()
+        self._frame += 1
         if self.world == 1:
             return self.renderer.untile(want_u8=want_u8, reuse=True)
-        dist.gather(self.shard, self._gather_views, dst=0)
-        if self.rank != 0:
-            return None, None
-        return self.renderer.untile(self._gather_buf, self._order, want_u8=want_u8, reuse=True)
+        prev = self._complete()
+        work = dist.gather(src, self._gather_views, dst=0, async_op=True)
+        self._pending = (work, want_u8)
+        return prev
+
+    def flush(self):
+        """Complete the frame whose gather is still in flight (world > 1); returns its images on rank 0."""
+        return self._complete()

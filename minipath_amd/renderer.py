@@ -182,6 +182,11 @@ class FrameRenderer:
         self.samples_per_frame = sum(t.area() for t in self.tiles) * settings.sample_count
         self.rays_per_frame = self.samples_per_frame  # reference semantics: one Object::intersect per sample
         self.segments = torch.zeros(1, dtype=torch.int64, device=self.device)  # ray segments of the last launch
+        # profile-guided hand-out order (mp_launch_extras): shader-clock cycles per tile accumulate here; rebalance() turns
+        # them into "expensive tiles first" for the following launches (tile i keeps rendering into slot i)
+        self.tile_cost = torch.zeros(max(len(self.tiles), 1), dtype=torch.int64, device=self.device)
+        self._order_c = None
+        self._extras = _lib.LaunchExtras(self.segments.data_ptr(), self.tile_cost.data_ptr(), None)
 
     def _stream(self):
         import torch
@@ -191,12 +196,23 @@ class FrameRenderer:
     def render(self):
         """One pass of the hot path over this renderer's tiles; asynchronous on the current stream."""
         _lib.check(
-            _lib.lib().mp_render_tiles_device_counted(
+            _lib.lib().mp_render_tiles_device_ex(
                 self.ctx.handle, self.scene.object.handle, C.byref(self._sampler), C.byref(self._st), self._tiles_c,
-                len(self.tiles), self.tile_buf.data_ptr(), self.segments.data_ptr(), self._stream(),
+                len(self.tiles), self.tile_buf.data_ptr(), C.byref(self._extras), self._stream(),
             )
         )
         return self.tile_buf
+
+    def rebalance(self) -> List[int]:
+        """Order the following launches' tile hand-out by the measured cost of the launches so far (most expensive first), and
+        reset the cost counters.  Synchronises the device (reads `tile_cost`).  The image does not depend on the order; the
+        tail of a launch does: waves that finish early find only cheap tiles left."""
+        cost = self.tile_cost[: len(self.tiles)].cpu().numpy()
+        order = sorted(range(len(self.tiles)), key=lambda i: (-int(cost[i]), i))
+        self._order_c = (C.c_uint32 * max(len(order), 1))(*order)
+        self._extras.tile_order = C.cast(self._order_c, C.POINTER(C.c_uint32)) if order else None
+        self.tile_cost.zero_()
+        return order
 
     def render_pass(self, begin: int, count: int = 0) -> int:
         """Progressive accumulation (MP_FLAG_ACCUMULATE): draws samples [begin, begin+count) of settings.sample_count
@@ -211,9 +227,9 @@ class FrameRenderer:
         st.flags |= _lib.MP_FLAG_ACCUMULATE
         st.pass_begin, st.pass_count = int(begin), int(count)
         _lib.check(
-            _lib.lib().mp_render_tiles_device_counted(
+            _lib.lib().mp_render_tiles_device_ex(
                 self.ctx.handle, self.scene.object.handle, C.byref(self._sampler), C.byref(st), self._tiles_c,
-                len(self.tiles), self.tile_buf.data_ptr(), self.segments.data_ptr(), self._stream(),
+                len(self.tiles), self.tile_buf.data_ptr(), C.byref(self._extras), self._stream(),
             )
         )
         return total if count == 0 else begin + count

@@ -635,6 +635,45 @@ def test_progressive_passes_equal_single_launch(teapot, tmp_path, max_depth, tra
     assert rc != 0
 
 
+@pytest.mark.parametrize("max_depth", [0, 4])
+def test_profile_guided_tile_order_same_image(teapot, max_depth):
+    """mp_launch_extras: tiles handed out in any order (here: by the measured cost of a first launch, then reversed) render the
+    same frame, the per-tile cost counters fill, and a non-permutation is refused."""
+    import ctypes as C
+
+    import torch
+
+    from minipath_amd import _lib
+
+    st = mp.RenderSettings(32, 9, (200, 136), seed=SEED, max_depth=max_depth)
+    fr = mp.FrameRenderer(teapot, mp.Camera.teapot_view(), st)
+    fr.render()
+    ref = fr.tile_buf.clone()
+    torch.cuda.synchronize()
+    cost = fr.tile_cost.cpu().numpy()
+    assert (cost[: len(fr.tiles)] > 0).all()
+    order = fr.rebalance()
+    assert sorted(order) == list(range(len(fr.tiles))) and int(fr.tile_cost.sum().item()) == 0
+    assert cost[order[0]] == cost.max()  # most expensive tile first
+    fr.tile_buf.zero_()
+    fr.render()
+    torch.cuda.synchronize()
+    assert torch.equal(fr.tile_buf.view(torch.int32), ref.view(torch.int32))
+    rev = order[::-1]
+    fr._order_c = (C.c_uint32 * len(rev))(*rev)
+    fr._extras.tile_order = C.cast(fr._order_c, C.POINTER(C.c_uint32))
+    fr.tile_buf.zero_()
+    fr.render()
+    torch.cuda.synchronize()
+    assert torch.equal(fr.tile_buf.view(torch.int32), ref.view(torch.int32))
+    bad = list(order)
+    bad[0] = bad[1]
+    fr._order_c = (C.c_uint32 * len(bad))(*bad)
+    fr._extras.tile_order = C.cast(fr._order_c, C.POINTER(C.c_uint32))
+    with pytest.raises(_lib.MinipathError):
+        fr.render()
+
+
 @pytest.mark.gpu
 def test_bench_two_rank_rehearsal():
     """bench.py's N > 1 path (shard plan, gather to rank 0, reassembly, max-over-ranks timing) with two ranks sharing this
