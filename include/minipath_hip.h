@@ -135,7 +135,9 @@ int mp_ctx_create(int device_id, mp_ctx **out);
 void mp_ctx_destroy(mp_ctx *ctx);
 int mp_ctx_device(const mp_ctx *ctx, int *device_id, int *cu_count);
 /* Tuning knobs.  "packet_stack_registers" (1..64, default 64): entries of the ray-packet walk's shared stack kept in registers; the
- * rest of the scene's stack bound lives in LDS.  Results never depend on it (tests lower it to cover the LDS path). */
+ * rest of the scene's stack bound lives in LDS.  "packet_samples_in_flight" (0 = automatic, or 1, 2, 4, ... 64): samples of one pixel
+ * a wavefront traces per pass (64 / value pixels side by side); sets the size of a work unit.  Results never depend on either
+ * (tests sweep them). */
 int mp_ctx_set_option(mp_ctx *ctx, const char *key, int value);
 
 /* ---- camera.rs ------------------------------------------------------------------------------------------ */

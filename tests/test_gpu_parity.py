@@ -635,6 +635,30 @@ def test_progressive_passes_equal_single_launch(teapot, tmp_path, max_depth, tra
     assert rc != 0
 
 
+def test_samples_in_flight_do_not_change_the_frame(teapot, oracle, teapot_oracle_bvh):
+    """The number of samples of a pixel a wavefront holds per pass (work-unit size; 16 = one DPP row with row_newbcast sums,
+    others through lane shuffles) must not change a single bit: the per-pixel sum stays sequential in sample order."""
+    import torch
+
+    res, spp = (72, 40), 37  # ragged: not a multiple of any S, clipped tiles
+    st = mp.RenderSettings(32, spp, res, seed=SEED)
+    cam = mp.Camera.teapot_view()
+    ctx = teapot.object.ctx
+    want, _, _, _, _ = teapot_oracle_bvh.render_image_mt(oracle.build_sampler(oracle.teapot_camera(), *res), res[0], res[1], spp, SEED, 32, 4)
+    try:
+        for s_in_flight in (1, 2, 4, 8, 16, 32, 64):
+            ctx.set_option("packet_samples_in_flight", s_in_flight)
+            fr = mp.FrameRenderer(teapot, cam, st)
+            fr.render()
+            img, _ = fr.untile()
+            torch.cuda.synchronize()
+            assert np.array_equal(bits(img.cpu().numpy()), bits(want)), s_in_flight
+        with pytest.raises(mp.MinipathError):
+            ctx.set_option("packet_samples_in_flight", 3)
+    finally:
+        ctx.set_option("packet_samples_in_flight", 0)
+
+
 @pytest.mark.parametrize("max_depth", [0, 4])
 def test_profile_guided_tile_order_same_image(teapot, max_depth):
     """mp_launch_extras: tiles handed out in any order (here: by the measured cost of a first launch, then reversed) render the
