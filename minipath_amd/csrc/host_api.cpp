@@ -58,7 +58,9 @@ struct mp_ctx {
     std::atomic<uint32_t> next_counter{0};
     std::atomic<uint32_t> packet_stack_regs{64};
     std::atomic<uint32_t> packet_samples{0};  // 0 = chosen by the launcher
-    uint32_t* take_counter() { return d_counters + (next_counter.fetch_add(1, std::memory_order_relaxed) % kCounters); }
+    uint32_t* take_counter() {  // one set of work-queue heads per launch in flight
+        return d_counters + static_cast<size_t>(next_counter.fetch_add(1, std::memory_order_relaxed) % kCounters) * kWorkQueues * kWorkQueueStride;
+    }
 };
 
 struct mp_scene {
@@ -316,8 +318,9 @@ int mp_ctx_create(int device_id, mp_ctx** out) {
     auto ctx = std::make_unique<mp_ctx>();
     ctx->device = device_id;
     ctx->cu_count = prop.multiProcessorCount;
-    MP_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), mp_ctx::kCounters * sizeof(uint32_t)));
-    MP_HIP(hipMemset(ctx->d_counters, 0, mp_ctx::kCounters * sizeof(uint32_t)));
+    const size_t counter_bytes = static_cast<size_t>(mp_ctx::kCounters) * kWorkQueues * kWorkQueueStride * sizeof(uint32_t);
+    MP_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_counters), counter_bytes));
+    MP_HIP(hipMemset(ctx->d_counters, 0, counter_bytes));
     *out = ctx.release();
     return MP_OK;
 }

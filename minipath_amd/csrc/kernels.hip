@@ -376,6 +376,25 @@ __device__ __forceinline__ void pixel_state_store(const RenderParams& P, size_t 
     *reinterpret_cast<float4*>(P.out + off) = make_float4(m, m, m, a);
 }
 
+// get_next_tile (machinery.rs:206-208) for wavefronts: kWorkQueues interleaved queues (mp_internal.h), home queue = this
+// workgroup's XCD, the others once it is empty.  Wave-uniform; `state` = queue | consecutive dry queues << 8 (one SGPR: the
+// packet kernel has none to spare).  Used as:  for (;;) { MP_NEXT_UNIT(unit); ... }
+#define MP_NEXT_UNIT(unit)                                                                              \
+    uint32_t unit;                                                                                      \
+    {                                                                                                   \
+        const uint32_t q_ = qstate & 0xFFu;                                                             \
+        uint32_t idx_ = 0;                                                                              \
+        if (lane == 0) idx_ = atomicAdd(P.counter + q_ * kWorkQueueStride, 1u);                         \
+        idx_ = __builtin_amdgcn_readfirstlane(idx_);                                                    \
+        unit = idx_ * kWorkQueues + q_;                                                                 \
+        if (unit >= total || idx_ >= 0x10000000u) {                                                     \
+            if ((qstate >> 8) + 1u == kWorkQueues) break;                                               \
+            qstate = ((q_ + 1u) % kWorkQueues) | (((qstate >> 8) + 1u) << 8);                           \
+            continue;                                                                                   \
+        }                                                                                               \
+        qstate = q_;                                                                                    \
+    }
+
 // S = samples of one pixel in flight in a wavefront (64/S pixels x S consecutive samples per pass).
 template <int S>
 __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
@@ -391,11 +410,9 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
     const uint64_t lanes_lt = (1ull << lane) - 1ull;
     const int pix = lane / S, sub = lane % S;
 
+    uint32_t qstate = blockIdx.x % kWorkQueues;
     for (;;) {
-        uint32_t unit = 0;
-        if (lane == 0) unit = atomicAdd(P.counter, 1u);
-        unit = __builtin_amdgcn_readfirstlane(unit);
-        if (unit >= total) break;
+        MP_NEXT_UNIT(unit)
         const uint32_t b = unit % upt;
         const uint32_t tile_i = P.tile_order ? P.tile_order[unit / upt] : unit / upt;
         const uint64_t t_unit = P.tile_cost ? __builtin_readcyclecounter() : 0;
@@ -746,6 +763,16 @@ __device__ __forceinline__ void add_samples_in_order(float& acc, float c, int la
         acc += c;
     } else if (S == 16) {
         RowSum<0, 16>::run(acc, c);
+    } else if (S == 32) {
+        // a pixel = two rows: every row adds its own 16 samples to the incoming sum (right for the even rows), row_bcast15 hands
+        // the even rows' result to the odd rows, which add their 16 samples (the even rows redo theirs: discarded), and the
+        // pixel's last lane holds the sum that all 32 lanes take over
+        RowSum<0, 16>::run(acc, c);
+        acc = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(acc), __float_as_int(acc), 0x142, 0xA, 0xF, false));
+        RowSum<0, 16>::run(acc, c);
+        const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 31));
+        const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(acc), 63));
+        acc = lane < 32 ? lo : hi;
     } else {
 #pragma unroll
         for (int j = 0; j < S; j++) acc += __shfl(c, (lane & ~(S - 1)) + j);
@@ -768,11 +795,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1));
     const uint32_t ts = P.tile_size;
     const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
+    uint32_t qstate = blockIdx.x % kWorkQueues;
     for (;;) {
-        uint32_t unit = 0;
-        if (lane == 0) unit = atomicAdd(P.counter, 1u);
-        unit = __builtin_amdgcn_readfirstlane(unit);
-        if (unit >= total) break;
+        MP_NEXT_UNIT(unit)
         const uint32_t b = unit % upt;
         const uint32_t tile_i = P.tile_order ? P.tile_order[unit / upt] : unit / upt;
         const uint64_t t_unit = P.tile_cost ? __builtin_readcyclecounter() : 0;
@@ -845,11 +870,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const uint32_t ts = P.tile_size;
     const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
     unsigned long long segs = 0;  // wave-uniform
+    uint32_t qstate = blockIdx.x % kWorkQueues;
     for (;;) {
-        uint32_t unit = 0;
-        if (lane == 0) unit = atomicAdd(P.counter, 1u);
-        unit = __builtin_amdgcn_readfirstlane(unit);
-        if (unit >= total) break;
+        MP_NEXT_UNIT(unit)
         const uint32_t b = unit % upt;
         const uint32_t tile_i = P.tile_order ? P.tile_order[unit / upt] : unit / upt;
         const uint64_t t_unit = P.tile_cost ? __builtin_readcyclecounter() : 0;
@@ -1123,7 +1146,7 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     P.lds_per_wave = lds_bytes_per_wave(L.scene.stack_cap);
     const uint32_t lds = P.lds_per_wave * 4;
     if (lds > 160 * 1024) { err = "scene too deep for the LDS traversal stacks"; return MP_ERR_UNSUPPORTED; }
-    int rc = check(hipMemsetAsync(L.d_counter, 0, sizeof(uint32_t), st), "hipMemsetAsync(counter)", err);
+    int rc = check(hipMemsetAsync(L.d_counter, 0, kWorkQueues * kWorkQueueStride * sizeof(uint32_t), st), "hipMemsetAsync(counter)", err);
     if (rc) return rc;
     const uint64_t units = static_cast<uint64_t>(L.n_tiles) * ((L.tile_size + 7) / 8) * ((L.tile_size + 7) / 8);
     const uint64_t want = (units + 3) / 4;
@@ -1148,6 +1171,8 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     // the work units 8x smaller than a whole 8x8 block (measured best on MI355X: profiles/r01_notes.md)
     const uint32_t nspp = L.pass_end - L.pass_begin;  // samples per pixel in this launch
     int S = nspp >= 16 ? 16 : nspp >= 8 ? 8 : nspp >= 4 ? 4 : nspp >= 2 ? 2 : 1;
+    // small launches (a rank's shard of a multi-GPU frame): 2-pixel units, so that the tail of the launch is half as long
+    if (nspp >= 32 && units * 16u < static_cast<uint64_t>(L.cu_count) * 32u * 24u) S = 32;
     if (L.packet_samples) S = static_cast<int>(std::min<uint32_t>(L.packet_samples, 64u));
     const bool lds_stack = L.scene.stack_cap > L.scene.packet_stack_regs;
     P.lds_per_wave = lds_stack ? ((L.scene.stack_cap - L.scene.packet_stack_regs) * 20u + 15u) & ~15u : 0u;
@@ -1163,6 +1188,7 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         else hipLaunchKernelGGL((render_tiles_packet_kernel<SV, false, W>), dim3(grid), dim3(256), 0, st, P);           \
     } while (0)
     if (S == 64) MP_LAUNCH_PACKET(64, 7);
+    else if (S == 32 && big) MP_LAUNCH_PACKET(32, 8);
     else if (S == 32) MP_LAUNCH_PACKET(32, 7);
     else if (S == 16 && big) MP_LAUNCH_PACKET(16, 8);
     else if (S == 16) MP_LAUNCH_PACKET(16, 7);

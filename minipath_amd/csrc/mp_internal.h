@@ -84,6 +84,12 @@ struct DevScene {
     float pre_min[3] = {0, 0, 0}, pre_max[3] = {0, 0, 0};
 };
 
+// A launch's work units are dealt to kWorkQueues interleaved queues (unit u belongs to queue u % kWorkQueues), one per XCD: a wave
+// draws from the queue of its XCD (workgroups go to XCDs round-robin) and moves on to the others when it runs dry.  One shared
+// counter saturates on same-address atomics from 8192 waves once units get small.  Each head sits on its own 128-byte line.
+constexpr uint32_t kWorkQueues = 8;
+constexpr uint32_t kWorkQueueStride = 32;  // dwords
+
 constexpr int kNodeDwords = 56;    // host staging rows: minx..maxz (8 floats each) + link[8]
 constexpr int kPacketDwords = 72;  // host staging rows: v0.xyz, e1.xyz, e2.xyz (8 floats each)
 
@@ -96,7 +102,7 @@ struct RenderLaunch {
     const mp_block* d_tiles;   // device copy of the tile list
     uint32_t n_tiles;
     float* d_out;              // tile-major f32 RGBA
-    uint32_t* d_counter;       // work-queue head, zeroed by the launcher
+    uint32_t* d_counter;       // kWorkQueues work-queue heads, kWorkQueueStride dwords apart, zeroed by the launcher
     int cu_count;
     int traversal;             // 0 = ray packets (coherent camera rays), 1 = 8-lane groups
     uint32_t max_depth;        // 0 = reference semantics (worker.rs:51-66); > 0 = build-defined path extension
