@@ -61,6 +61,21 @@ struct mp_ctx {
     uint32_t* take_counter() {  // one set of work-queue heads per launch in flight
         return d_counters + static_cast<size_t>(next_counter.fetch_add(1, std::memory_order_relaxed) % kCounters) * kWorkQueues * kWorkQueueStride;
     }
+    // Device copies of the tile lists (and hand-out orders) callers pass as host arrays.  A frame loop passes the same list every
+    // frame: uploading it per launch would put a pageable host-to-device copy in the stream, which blocks the calling thread
+    // until the stream has drained (measured: a full frame) and so serialises host and GPU.  Entries are compared by content.
+    struct TileList {
+        std::vector<mp_block> tiles;
+        std::vector<uint32_t> order;
+        unsigned char* d_buf = nullptr;  // tiles, then order
+        uint64_t last_use = 0;
+    };
+    static constexpr size_t kTileLists = 32;
+    std::mutex tile_mutex;
+    std::vector<TileList> tile_lists;
+    uint64_t tile_clock = 0;
+    // Returns device pointers valid until the entry is evicted; eviction frees with hipFree, which waits for the device.
+    int device_tiles(const mp_block* tiles, size_t n, const uint32_t* order, const mp_block** d_tiles, const uint32_t** d_order);
 };
 
 struct mp_scene {
@@ -89,6 +104,47 @@ struct DeviceGuard {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+
+}  // namespace
+
+int mp_ctx::device_tiles(const mp_block* tiles, size_t n, const uint32_t* order, const mp_block** d_tiles, const uint32_t** d_order) {
+    std::lock_guard<std::mutex> lock(tile_mutex);
+    const size_t tb = n * sizeof(mp_block), ob = order ? n * sizeof(uint32_t) : 0;
+    TileList* hit = nullptr;
+    for (TileList& e : tile_lists)
+        if (e.tiles.size() == n && e.order.size() == (order ? n : 0) && std::memcmp(e.tiles.data(), tiles, tb) == 0 &&
+            (!order || std::memcmp(e.order.data(), order, ob) == 0)) {
+            hit = &e;
+            break;
+        }
+    if (!hit) {
+        if (tile_lists.size() >= kTileLists) {  // evict the least recently used list
+            size_t lru = 0;
+            for (size_t i = 1; i < tile_lists.size(); i++)
+                if (tile_lists[i].last_use < tile_lists[lru].last_use) lru = i;
+            (void)hipFree(tile_lists[lru].d_buf);
+            tile_lists.erase(tile_lists.begin() + static_cast<std::ptrdiff_t>(lru));
+        }
+        TileList e;
+        e.tiles.assign(tiles, tiles + n);
+        if (order) e.order.assign(order, order + n);
+        MP_HIP(hipMalloc(reinterpret_cast<void**>(&e.d_buf), tb + ob));
+        hipError_t err = hipMemcpy(e.d_buf, tiles, tb, hipMemcpyHostToDevice);
+        if (err == hipSuccess && order) err = hipMemcpy(e.d_buf + tb, order, ob, hipMemcpyHostToDevice);
+        if (err != hipSuccess) {
+            (void)hipFree(e.d_buf);
+            return hip_fail(err, "hipMemcpy(tile list)");
+        }
+        tile_lists.push_back(std::move(e));
+        hit = &tile_lists.back();
+    }
+    hit->last_use = ++tile_clock;
+    *d_tiles = reinterpret_cast<const mp_block*>(hit->d_buf);
+    if (d_order) *d_order = order ? reinterpret_cast<const uint32_t*>(hit->d_buf + tb) : nullptr;
+    return MP_OK;
+}
+
+namespace {
 
 int upload_scene(mp_scene* s) {
     const HostBvh& h = s->host;
@@ -329,6 +385,7 @@ void mp_ctx_destroy(mp_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    for (auto& e : ctx->tile_lists) (void)hipFree(e.d_buf);
     delete ctx;
 }
 
@@ -544,17 +601,10 @@ int mp_render_tiles_device_ex(mp_ctx* ctx, const mp_scene* scene, const mp_camer
         }
     }
     DeviceGuard g(ctx->device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    // one staging buffer: the tile list, then (optionally) the hand-out order
-    const size_t tiles_bytes = n_tiles * sizeof(mp_block), order_bytes = tile_order ? n_tiles * sizeof(uint32_t) : 0;
-    unsigned char* d_stage = nullptr;
-    MP_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_stage), tiles_bytes + order_bytes, st));
-    mp_block* d_tiles = reinterpret_cast<mp_block*>(d_stage);
-    uint32_t* d_order = tile_order ? reinterpret_cast<uint32_t*>(d_stage + tiles_bytes) : nullptr;
-    hipError_t e = hipMemcpyAsync(d_tiles, tiles, tiles_bytes, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess && tile_order) e = hipMemcpyAsync(d_order, tile_order, order_bytes, hipMemcpyHostToDevice, st);
-    int rc = MP_OK;
-    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(tiles)");
+    const mp_block* d_tiles = nullptr;
+    const uint32_t* d_order = nullptr;
+    int rc = ctx->device_tiles(tiles, n_tiles, tile_order, &d_tiles, &d_order);
+    if (rc) return rc;
     if (!rc && d_ray_segments) {
         uint64_t init = 0;
         if (!(settings->flags & MP_FLAG_PATHS))  // reference semantics: one Object::intersect per sample
@@ -565,7 +615,6 @@ int mp_render_tiles_device_ex(mp_ctx* ctx, const mp_scene* scene, const mp_camer
         if (rc) fail(rc, err);
     }
     if (!rc) rc = render_tiles_device(ctx, scene, *sampler, *settings, d_tiles, n_tiles, d_rgba_f32, stream, d_ray_segments, d_order, d_tile_cost);
-    (void)hipFreeAsync(d_stage, st);
     return rc;
 }
 
@@ -574,20 +623,15 @@ int mp_untile(mp_ctx* ctx, const mp_settings* settings, const mp_block* tiles, s
     if (!ctx || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
     if (n_tiles == 0) return MP_OK;
     if (!tiles || !d_tiles_f32) return fail(MP_ERR_INVALID, "NULL tiles/input");
+    if (n_tiles > 0xFFFFFFFFull) return fail(MP_ERR_INVALID, "too many tiles");
     DeviceGuard g(ctx->device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    mp_block* d_tiles = nullptr;
-    MP_HIP(hipMallocAsync(reinterpret_cast<void**>(&d_tiles), n_tiles * sizeof(mp_block), st));
-    hipError_t e = hipMemcpyAsync(d_tiles, tiles, n_tiles * sizeof(mp_block), hipMemcpyHostToDevice, st);
-    int rc = MP_OK;
+    const mp_block* d_tiles = nullptr;
+    int rc = ctx->device_tiles(tiles, n_tiles, nullptr, &d_tiles, nullptr);  // cached: no per-frame upload
+    if (rc) return rc;
     std::string err;
-    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpyAsync(tiles)");
-    if (!rc) {
-        rc = launch_untile(settings->width, settings->height, settings->tile_size, d_tiles, static_cast<uint32_t>(n_tiles),
-                           d_tiles_f32, d_image_f32, d_image_u8, stream, err);
-        if (rc) fail(rc, err);
-    }
-    (void)hipFreeAsync(d_tiles, st);
+    rc = launch_untile(settings->width, settings->height, settings->tile_size, d_tiles, static_cast<uint32_t>(n_tiles), d_tiles_f32,
+                       d_image_f32, d_image_u8, stream, err);
+    if (rc) fail(rc, err);
     return rc;
 }
 
