@@ -856,6 +856,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 constexpr float kPathAlbedo = 0.75f;
 constexpr float kPathEps = 1e-4f;
 
+// One path vertex of the build-defined extension (oracle: render_sample_paths_impl), shared by the fused and the staged kernels so
+// that both evaluate the very same operations: `h` is the closest hit of segment `depth` along `r`.  Updates L / thr, and either
+// ends the path (returns false) or replaces `r` by the bounce ray drawn from `rng` (returns true).
+__device__ __forceinline__ bool path_vertex(const DevScene& sc, const PacketHit& h, uint32_t depth, uint32_t max_depth, Rng& rng,
+                                            Ray& r, float& L, float& thr, bool& primary_hit) {
+    if (h.prim == kNoPrim) {
+        L = thr;  // sky radiance 1
+        return false;
+    }
+    if (depth == 1) primary_hit = true;
+    float n[3];
+    resolve_normal(sc, h.prim, h.u, h.v, n);
+    const float dn = r.dx * n[0] + r.dy * n[1] + r.dz * n[2];
+    if (dn > 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    thr = thr * kPathAlbedo;
+    if (depth == max_depth) return false;
+    const float hx = r.ox + r.dx * h.t, hy = r.oy + r.dy * h.t, hz = r.oz + r.dz * h.t;  // geometry/mod.rs:56-58
+    float x1, x2;
+    unit_disc(rng, x1, x2);
+    const float z = sqrtf(1.0f - (x1 * x1 + x2 * x2));
+    const float sign = copysignf(1.0f, n[2]);
+    const float a = -1.0f / (sign + n[2]);
+    const float bb = n[0] * n[1] * a;
+    const float t0 = 1.0f + sign * n[0] * n[0] * a, t1 = sign * bb, t2 = -sign * n[0];
+    const float b0 = bb, b1 = sign + n[1] * n[1] * a, b2 = -n[1];
+    ray_new(hx + n[0] * kPathEps, hy + n[1] * kPathEps, hz + n[2] * kPathEps, t0 * x1 + b0 * x2 + n[0] * z,
+            t1 * x1 + b1 * x2 + n[1] * z, t2 * x1 + b2 * x2 + n[2] * z, r);
+    return true;
+}
+
 template <int S>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void render_paths_kernel(RenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -928,34 +958,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                     }
                     wave_lds_sync();
                 }
-                if (alive) {
-                    if (h.prim == kNoPrim) {
-                        L = thr;  // sky radiance 1
-                        alive = false;
-                    } else {
-                        if (depth == 1) primary_hit = true;
-                        float n[3];
-                        resolve_normal(P.scene, h.prim, h.u, h.v, n);
-                        const float dn = r.dx * n[0] + r.dy * n[1] + r.dz * n[2];
-                        if (dn > 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-                        thr = thr * kPathAlbedo;
-                        if (depth == P.max_depth) {
-                            alive = false;
-                        } else {
-                            const float hx = r.ox + r.dx * h.t, hy = r.oy + r.dy * h.t, hz = r.oz + r.dz * h.t;  // geometry/mod.rs:56-58
-                            float x1, x2;
-                            unit_disc(rng, x1, x2);
-                            const float z = sqrtf(1.0f - (x1 * x1 + x2 * x2));
-                            const float sign = copysignf(1.0f, n[2]);
-                            const float a = -1.0f / (sign + n[2]);
-                            const float bb = n[0] * n[1] * a;
-                            const float t0 = 1.0f + sign * n[0] * n[0] * a, t1 = sign * bb, t2 = -sign * n[0];
-                            const float b0 = bb, b1 = sign + n[1] * n[1] * a, b2 = -n[1];
-                            ray_new(hx + n[0] * kPathEps, hy + n[1] * kPathEps, hz + n[2] * kPathEps, t0 * x1 + b0 * x2 + n[0] * z,
-                                    t1 * x1 + b1 * x2 + n[1] * z, t2 * x1 + b2 * x2 + n[2] * z, r);
-                        }
-                    }
-                }
+                if (alive) alive = path_vertex(P.scene, h, depth, P.max_depth, rng, r, L, thr, primary_hit);
             }
             cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
             add_samples_in_order<S>(acc, L, lane);
