@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on cpu_baseline worker threads")
     ap.add_argument("--traversal", default="packets", choices=["packets", "groups"])
     ap.add_argument("--depth", type=int, default=0, help="0 = reference semantics (default); N >= 1 = build-defined path extension with at most N segments")
+    ap.add_argument("--wavefront", action="store_true", help="with --depth N: staged evaluation, bounce rays sorted into packets")
     ap.add_argument("--no-extension", action="store_true", help="skip the extra 'paths_depth8' measurement")
     ap.add_argument("--check", action="store_true", help="compare a few tiles of the GPU frame with the oracle")
     return ap.parse_args()
@@ -142,7 +143,8 @@ def main():
     else:
         scene = mp.Scene(mp.TriangleBvh.with_obj(args.scene, ctx))
         cam = mp.Camera.teapot_view()
-    st = mp.RenderSettings(args.tile, args.spp, (args.width, args.height), seed=args.seed, traversal=args.traversal, max_depth=args.depth)
+    st = mp.RenderSettings(args.tile, args.spp, (args.width, args.height), seed=args.seed, traversal=args.traversal, max_depth=args.depth,
+                           wavefront=args.wavefront)
     frame = DistributedFrame(scene, cam, st, rank, world)
     all_tiles = frame.all_tiles
     total_rays = args.width * args.height * args.spp

@@ -97,6 +97,12 @@ typedef struct {
  * sample_count and s), so any split of the samples over launches is bit-identical to one launch; the buffer plus the next
  * pass_begin is the checkpoint (minipath_amd.io.save_checkpoint). */
 #define MP_FLAG_ACCUMULATE 8u
+/* With MP_FLAG_PATHS: staged ("wavefront") evaluation.  The paths of a batch of tiles live in HBM as SoA streams (RNG state, ray,
+ * throughput, hit); between two segments the live paths are counting-sorted by (tile, direction bin) so that every wavefront
+ * walks 64 rays that start close together and leave in similar directions as ONE packet, instead of eight lanes per incoherent
+ * ray.  Same frame, bit for bit, as without the flag (each ray's result is independent of its packet; the per-pixel sum is taken
+ * in sample order at the end).  tile_order / d_tile_cost of mp_launch_extras are ignored in this mode. */
+#define MP_FLAG_WAVEFRONT 16u
 
 /* machinery.rs:180-189 RenderProgressSnapshot */
 typedef struct { size_t finished, total; } mp_progress;

@@ -18,6 +18,7 @@ MP_FLAG_SHUFFLE_TILES = 1
 MP_FLAG_TRAVERSAL_GROUPS = 2
 MP_FLAG_PATHS = 4
 MP_FLAG_ACCUMULATE = 8
+MP_FLAG_WAVEFRONT = 16
 
 
 class MinipathError(RuntimeError):

@@ -312,6 +312,7 @@ bool valid_settings(const mp_settings* st) {
     if (!(st && st->tile_size > 0 && st->sample_count > 0 && st->width > 0 && st->height > 0 &&
           (!(st->flags & MP_FLAG_PATHS) || st->max_depth >= 1)))
         return false;
+    if ((st->flags & MP_FLAG_WAVEFRONT) && !(st->flags & MP_FLAG_PATHS)) return false;
     if (!(st->flags & MP_FLAG_ACCUMULATE)) return st->pass_begin == 0 && st->pass_count == 0;
     return st->pass_begin < st->sample_count && st->pass_count <= st->sample_count - st->pass_begin;
 }
@@ -350,7 +351,7 @@ int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_samp
     L.carry_in = L.pass_begin > 0;
     L.finalize = L.pass_end == st.sample_count;
     std::string err;
-    int rc = launch_render_tiles(L, stream, err);
+    int rc = (st.flags & MP_FLAG_WAVEFRONT) ? launch_render_paths_wavefront(L, stream, err) : launch_render_tiles(L, stream, err);
     if (rc) return fail(rc, err);
     return MP_OK;
 }

@@ -969,6 +969,267 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     if (lane == 0 && P.segments && segs) atomicAdd(P.segments, segs);
 }
 
+// ---- staged ("wavefront") evaluation of the path extension: MP_FLAG_WAVEFRONT --------------------------------------
+// The north star's formulation, kept beside the fused render_paths_kernel: the paths of a batch (a few tiles x a chunk of
+// samples, ~2 M paths) live in HBM as SoA streams (RNG state, ray, throughput, radiance, hit); per segment: a vertex kernel
+// (shade + bounce, one thread per path), a counting sort of the live paths by (tile, direction bin) = stream compaction, and a
+// trace kernel over the sorted stream.  Per-path RNG stream and operations are those of the fused kernel (path_vertex), every
+// ray's result is independent of its neighbours, and the per-pixel sum is taken in sample order at the end: the frame is
+// bit-identical to the fused kernel's and the oracle's (the two pipelines cross-check each other in the tests).  Measured slower
+// than the fused kernel, which therefore stays the default.
+constexpr uint32_t kDirBins = 512;  // 8 octants x 8 x 8 cells of the octahedral map of |d|
+
+struct WfState {
+    uint64_t* rng;       // 4 rows x n
+    float* ray;          // 6 rows x n : origin, unit direction
+    float* thr;          // n
+    float* L;            // n
+    float* hit_t;        // n
+    uint32_t* hit_prim;  // n
+    float* hit_u;        // n
+    float* hit_v;        // n
+    uint32_t* flags;     // n : kWfAlive | kWfPrimaryHit | kWfValid
+    uint32_t* key;       // n : sort key of a live path
+    uint32_t* idx;       // n : live paths in key order
+    uint32_t* hist;      // nbins + 1 : per-key counts of the segment being generated ; [nbins] unused
+    uint32_t* offs;      // nbins + 1 : exclusive scan of hist ; [nbins] = number of live paths
+    uint32_t* cursor;    // nbins
+    uint32_t n, nbins;
+};
+constexpr uint32_t kWfAlive = 1u, kWfPrimaryHit = 2u, kWfValid = 4u;
+
+struct WfParams {
+    DevScene scene;
+    RayGen gen;
+    const mp_block* tiles;  // this batch's tiles (device)
+    uint32_t n_tiles, tile_size;
+    uint32_t tile_base;     // index of the batch's first tile in the caller's tile list (output slot)
+    uint32_t s0, sc, s_end; // the chunk covers samples [s0, min(s0 + sc, s_end))
+    uint32_t depth, max_depth;
+    float* out;
+    float inv_spp;
+    uint32_t carry_in, finalize;
+    uint32_t lds_per_wave;
+    unsigned long long* segments;
+    WfState st;
+};
+
+__device__ __forceinline__ uint32_t direction_bin(float dx, float dy, float dz) {
+    const float ax = fabsf(dx), ay = fabsf(dy), az = fabsf(dz);
+    const float inv = __builtin_amdgcn_rcpf(ax + ay + az);  // approximate: the bin only steers the sort
+    const uint32_t qx = min(7u, static_cast<uint32_t>(ax * inv * 8.0f)), qy = min(7u, static_cast<uint32_t>(ay * inv * 8.0f));
+    const uint32_t oct = (dx < 0.0f ? 1u : 0u) | (dy < 0.0f ? 2u : 0u) | (dz < 0.0f ? 4u : 0u);
+    return oct * 64u + qx * 8u + qy;
+}
+
+// path p = (tile_local * ts*ts + (y - min_y) * ts + (x - min_x)) * sc + (s - s0)
+// Stage 1: camera rays, generated and walked as packets of 2x2 pixels x 16 samples like render_tiles_packet_kernel.
+template <bool LDS_STACK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void wf_camera_kernel(WfParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int S = 16, BW = 2, BH = 2;
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const int pix = lane / S, sub = lane % S;
+    const uint32_t ts = P.tile_size, bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
+    const uint32_t n = P.st.n;
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    unsigned long long segs = 0;  // camera segments of this wave (wave-uniform)
+    for (uint32_t unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); unit < total; unit += n_waves) {
+        const uint32_t tile_l = unit / upt, b = unit % upt;
+        const mp_block T = P.tiles[tile_l];
+        const uint32_t px = T.min_x + (b % bx) * BW + static_cast<uint32_t>(pix % BW);
+        const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
+        const bool inpix = px < T.max_x && py < T.max_y;
+        const uint32_t pbase = ((tile_l * ts + (py - T.min_y)) * ts + (px - T.min_x)) * P.sc;
+        for (uint32_t sl0 = 0; sl0 < P.sc; sl0 += S) {
+            const uint32_t sl = sl0 + static_cast<uint32_t>(sub), s = P.s0 + sl;
+            const bool slot = inpix && sl < P.sc;       // a path slot of the batch exists for this lane
+            const bool act = slot && s < P.s_end;       // ... and holds a sample of this launch
+            Rng rng;
+            rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+            Ray r;
+            r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+            if (act) {
+                rng_seed(rng, sample_key(P.gen, px, py, s));
+                sample_ray_rng(P.gen, px, py, rng, r);
+            }
+            segs += static_cast<unsigned long long>(__popcll(__ballot(act)));
+            PacketHit h;
+            h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
+            const bool go = act && may_hit_scene(P.scene, r);
+            if (__ballot(go) != 0) {
+                float* lds = reinterpret_cast<float*>(smem + static_cast<size_t>(static_cast<int>(threadIdx.x) >> 6) * P.lds_per_wave);
+                if (LDS_STACK) {
+                    HybridStack st(lds, lane, P.scene.stack_cap, P.scene.packet_stack_regs);
+                    trace_packet<false>(P.scene, r, go, st, h);
+                } else {
+                    RegStack st(lds, lane);
+                    trace_packet<true>(P.scene, r, go, st, h);
+                }
+            }
+            if (slot) {
+                const uint32_t p = pbase + sl;
+                P.st.flags[p] = act ? (kWfAlive | kWfValid) : 0u;
+                if (act) {
+                    P.st.rng[0 * static_cast<size_t>(n) + p] = rng.s0; P.st.rng[1 * static_cast<size_t>(n) + p] = rng.s1;
+                    P.st.rng[2 * static_cast<size_t>(n) + p] = rng.s2; P.st.rng[3 * static_cast<size_t>(n) + p] = rng.s3;
+                    P.st.ray[0 * static_cast<size_t>(n) + p] = r.ox; P.st.ray[1 * static_cast<size_t>(n) + p] = r.oy;
+                    P.st.ray[2 * static_cast<size_t>(n) + p] = r.oz; P.st.ray[3 * static_cast<size_t>(n) + p] = r.dx;
+                    P.st.ray[4 * static_cast<size_t>(n) + p] = r.dy; P.st.ray[5 * static_cast<size_t>(n) + p] = r.dz;
+                    P.st.thr[p] = 1.0f;
+                    P.st.L[p] = 0.0f;
+                    P.st.hit_t[p] = h.t; P.st.hit_prim[p] = h.prim; P.st.hit_u[p] = h.u; P.st.hit_v[p] = h.v;
+                }
+            }
+        }
+    }
+    if (lane == 0 && P.segments && segs) atomicAdd(P.segments, segs);
+}
+
+// Stage 2: one thread per path: shade the hit of segment P.depth, draw the bounce ray, count it under its sort key.
+__global__ __launch_bounds__(256) void wf_vertex_kernel(WfParams P) {
+    const uint32_t n = P.st.n;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        uint32_t fl = P.st.flags[p];
+        if (!(fl & kWfAlive)) continue;
+        Rng rng;
+        rng.s0 = P.st.rng[0 * static_cast<size_t>(n) + p]; rng.s1 = P.st.rng[1 * static_cast<size_t>(n) + p];
+        rng.s2 = P.st.rng[2 * static_cast<size_t>(n) + p]; rng.s3 = P.st.rng[3 * static_cast<size_t>(n) + p];
+        Ray r;
+        r.ox = P.st.ray[0 * static_cast<size_t>(n) + p]; r.oy = P.st.ray[1 * static_cast<size_t>(n) + p];
+        r.oz = P.st.ray[2 * static_cast<size_t>(n) + p]; r.dx = P.st.ray[3 * static_cast<size_t>(n) + p];
+        r.dy = P.st.ray[4 * static_cast<size_t>(n) + p]; r.dz = P.st.ray[5 * static_cast<size_t>(n) + p];
+        r.ix = r.iy = r.iz = 0.0f;  // not used by path_vertex
+        PacketHit h;
+        h.t = P.st.hit_t[p]; h.prim = P.st.hit_prim[p]; h.u = P.st.hit_u[p]; h.v = P.st.hit_v[p];
+        float L = P.st.L[p], thr = P.st.thr[p];
+        bool primary = (fl & kWfPrimaryHit) != 0u;
+        const bool alive = path_vertex(P.scene, h, P.depth, P.max_depth, rng, r, L, thr, primary);
+        fl = (fl & ~(kWfAlive | kWfPrimaryHit)) | (alive ? kWfAlive : 0u) | (primary ? kWfPrimaryHit : 0u);
+        P.st.flags[p] = fl;
+        P.st.L[p] = L;
+        P.st.thr[p] = thr;
+        if (alive) {
+            P.st.rng[0 * static_cast<size_t>(n) + p] = rng.s0; P.st.rng[1 * static_cast<size_t>(n) + p] = rng.s1;
+            P.st.rng[2 * static_cast<size_t>(n) + p] = rng.s2; P.st.rng[3 * static_cast<size_t>(n) + p] = rng.s3;
+            P.st.ray[0 * static_cast<size_t>(n) + p] = r.ox; P.st.ray[1 * static_cast<size_t>(n) + p] = r.oy;
+            P.st.ray[2 * static_cast<size_t>(n) + p] = r.oz; P.st.ray[3 * static_cast<size_t>(n) + p] = r.dx;
+            P.st.ray[4 * static_cast<size_t>(n) + p] = r.dy; P.st.ray[5 * static_cast<size_t>(n) + p] = r.dz;
+            const uint32_t tile_l = p / (P.tile_size * P.tile_size * P.sc);
+            const uint32_t k = tile_l * kDirBins + direction_bin(r.dx, r.dy, r.dz);
+            P.st.key[p] = k;
+            atomicAdd(P.st.hist + k, 1u);
+        }
+    }
+}
+
+// Stage 3: exclusive scan of the key histogram (one workgroup), cursors and histogram reset for the next segment, and the
+// number of live paths = ray segments of the next stage.
+__global__ __launch_bounds__(1024) void wf_scan_kernel(WfParams P) {
+    __shared__ uint32_t part[1024];
+    const uint32_t nb = P.st.nbins, per = (nb + 1023u) / 1024u, t = threadIdx.x;
+    uint32_t sum = 0;
+    for (uint32_t i = t * per; i < min(nb, (t + 1u) * per); i++) sum += P.st.hist[i];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {  // Hillis-Steele inclusive scan of the per-thread sums
+        const uint32_t v = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t i = t * per; i < min(nb, (t + 1u) * per); i++) {
+        const uint32_t c = P.st.hist[i];
+        P.st.offs[i] = run;
+        P.st.cursor[i] = 0u;
+        P.st.hist[i] = 0u;
+        run += c;
+    }
+    if (t == 1023u) {
+        P.st.offs[nb] = part[1023];
+        if (P.segments) atomicAdd(P.segments, static_cast<unsigned long long>(part[1023]));
+    }
+}
+
+// Stage 4: scatter the live paths to their key's range (order inside a key is arbitrary: results do not depend on it).
+__global__ __launch_bounds__(256) void wf_scatter_kernel(WfParams P) {
+    const uint32_t n = P.st.n;
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        if (!(P.st.flags[p] & kWfAlive)) continue;
+        const uint32_t k = P.st.key[p];
+        P.st.idx[P.st.offs[k] + atomicAdd(P.st.cursor + k, 1u)] = p;
+    }
+}
+
+// Stage 5: the sorted rays through the 8-lane-group traversal, 64 per wave.  (Walking 64 sorted rays as ONE packet was measured
+// too: diffuse bounce rays do not share enough of the tree even when sorted -- 2 586 VALU per ray against ~500 here; see
+// profiles/r01_notes.md.)  The sort serves cache locality.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void wf_trace_groups_kernel(WfParams P) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
+    float* q = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P.lds_per_wave);
+    uint2* stack = reinterpret_cast<uint2*>(q + kQueueFloats);
+    const uint32_t n = P.st.n, live = P.st.offs[P.st.nbins];
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6), chunks = (live + 63u) / 64u;
+    for (uint32_t c = blockIdx.x * (blockDim.x >> 6) + static_cast<uint32_t>(wave); c < chunks; c += n_waves) {
+        const uint32_t slot = c * 64u + static_cast<uint32_t>(lane);
+        const bool act = slot < live;
+        const uint32_t p = act ? P.st.idx[slot] : 0u;
+        Ray r;
+        r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+        if (act) {
+            r.ox = P.st.ray[0 * static_cast<size_t>(n) + p]; r.oy = P.st.ray[1 * static_cast<size_t>(n) + p];
+            r.oz = P.st.ray[2 * static_cast<size_t>(n) + p]; r.dx = P.st.ray[3 * static_cast<size_t>(n) + p];
+            r.dy = P.st.ray[4 * static_cast<size_t>(n) + p]; r.dz = P.st.ray[5 * static_cast<size_t>(n) + p];
+            r.ix = (r.dx == 0.0f) ? INFINITY : 1.0f / r.dx;
+            r.iy = (r.dy == 0.0f) ? INFINITY : 1.0f / r.dy;
+            r.iz = (r.dz == 0.0f) ? INFINITY : 1.0f / r.dz;
+        }
+        const bool go = act && may_hit_scene(P.scene, r);
+        const uint64_t gm = __ballot(go);
+        const int cnt = __popcll(gm), rank = __popcll(gm & ((1ull << lane) - 1ull));
+        if (go) {
+            q[0 * 64 + rank] = r.ox; q[1 * 64 + rank] = r.oy; q[2 * 64 + rank] = r.oz;
+            q[3 * 64 + rank] = r.dx; q[4 * 64 + rank] = r.dy; q[5 * 64 + rank] = r.dz;
+        }
+        wave_lds_sync();
+        trace_wave(P.scene, q, stack, cnt);
+        if (act) {
+            P.st.hit_t[p] = go ? q[0 * 64 + rank] : FLT_MAX;
+            P.st.hit_prim[p] = go ? as_u(q[1 * 64 + rank]) : kNoPrim;
+            P.st.hit_u[p] = go ? q[2 * 64 + rank] : 0.0f;
+            P.st.hit_v[p] = go ? q[3 * 64 + rank] : 0.0f;
+        }
+        wave_lds_sync();
+    }
+}
+
+// Stage 6: pixel_sum += sample in sample order (worker.rs:41-43), one thread per pixel of the batch.
+__global__ __launch_bounds__(256) void wf_accumulate_kernel(WfParams P) {
+    const uint32_t ts = P.tile_size, npx = P.n_tiles * ts * ts;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+        const uint32_t tile_l = i / (ts * ts), q = i % (ts * ts), x = q % ts, y = q / ts;
+        const mp_block T = P.tiles[tile_l];
+        if (!(T.min_x + x < T.max_x && T.min_y + y < T.max_y)) continue;
+        float* o = P.out + (static_cast<size_t>(P.tile_base + tile_l) * ts * ts + q) * 4;
+        float acc = 0.0f, cnt = 0.0f;
+        if (P.carry_in) {
+            const float4 prev = *reinterpret_cast<const float4*>(o);
+            acc = prev.x;
+            cnt = prev.w;
+        }
+        const uint32_t ns = min(P.sc, P.s_end - P.s0);
+        const uint32_t pbase = i * P.sc;
+        for (uint32_t sl = 0; sl < ns; sl++) {
+            acc += P.st.L[pbase + sl];
+            cnt += (P.st.flags[pbase + sl] & kWfPrimaryHit) ? 1.0f : 0.0f;
+        }
+        const float m = P.finalize ? acc * P.inv_spp : acc, a = P.finalize ? cnt * P.inv_spp : cnt;
+        *reinterpret_cast<float4*>(o) = make_float4(m, m, m, a);
+    }
+}
+
 // ---- batched Object::intersect over SoA ray streams (ray_bvh_intersection.rs:26-96) -------------------------
 struct TraceParams {
     DevScene scene;
@@ -1201,6 +1462,102 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     else MP_LAUNCH_PACKET(1, 7);
 #undef MP_LAUNCH_PACKET
     return check(hipGetLastError(), "render_tiles_packet_kernel launch", err);
+}
+
+int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::string& err) {
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (L.n_tiles == 0) return MP_OK;
+    if (L.scene.kind != 0u || L.max_depth == 0) { err = "the staged path evaluation needs MP_FLAG_PATHS and a TriangleBvh scene"; return MP_ERR_UNSUPPORTED; }
+    WfParams P;
+    P.scene = L.scene;
+    P.gen.s = L.sampler;
+    P.gen.jitter_scale = uniform_inclusive_scale(-0.5f, 0.5f);
+    P.gen.width = L.width;
+    P.gen.spp = L.spp;
+    P.gen.seed = L.seed;
+    P.tile_size = L.tile_size;
+    P.max_depth = L.max_depth;
+    P.out = L.d_out;
+    P.inv_spp = 1.0f / static_cast<float>(L.spp);
+    P.segments = L.d_segments;
+    const bool lds_stack = L.scene.stack_cap > L.scene.packet_stack_regs;
+    P.lds_per_wave = lds_stack ? ((L.scene.stack_cap - L.scene.packet_stack_regs) * 20u + 15u) & ~15u : 0u;
+    const uint32_t plds = P.lds_per_wave * 4;
+    if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
+    const uint32_t per_cu = plds ? std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds)) : 8u;
+    // a batch = tb tiles x sc samples, about two million paths: enough rays per (tile, direction bin) to fill packets
+    const uint32_t ts = L.tile_size, nspp = L.pass_end - L.pass_begin;
+    const uint32_t sc = std::min<uint32_t>(nspp, 64u);
+    const uint64_t per_tile = static_cast<uint64_t>(ts) * ts * sc;
+    if (per_tile > (1ull << 28)) { err = "tile_size too large for the staged path evaluation"; return MP_ERR_UNSUPPORTED; }
+    const uint32_t tb = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(L.n_tiles, (1ull << 21) / per_tile)));
+    const uint32_t n_max = static_cast<uint32_t>(per_tile * tb), nbins = tb * kDirBins;
+    // workspace: rng 32 + ray 24 + thr, L 8 + hit 16 + flags, key, idx 12 = 92 bytes per path, stream-ordered allocation
+    const size_t n64 = (static_cast<size_t>(n_max) + 63) & ~static_cast<size_t>(63);
+    const size_t bytes = n64 * 92 + (static_cast<size_t>(nbins) + 64) * 4 * 3;
+    unsigned char* ws = nullptr;
+    int rc = check(hipMallocAsync(reinterpret_cast<void**>(&ws), bytes, st), "hipMallocAsync(path state)", err);
+    if (rc) return rc;
+    unsigned char* w = ws;
+    auto take = [&](size_t b) { unsigned char* r = w; w += b; return r; };
+    P.st.rng = reinterpret_cast<uint64_t*>(take(n64 * 32));
+    P.st.ray = reinterpret_cast<float*>(take(n64 * 24));
+    P.st.thr = reinterpret_cast<float*>(take(n64 * 4));
+    P.st.L = reinterpret_cast<float*>(take(n64 * 4));
+    P.st.hit_t = reinterpret_cast<float*>(take(n64 * 4));
+    P.st.hit_prim = reinterpret_cast<uint32_t*>(take(n64 * 4));
+    P.st.hit_u = reinterpret_cast<float*>(take(n64 * 4));
+    P.st.hit_v = reinterpret_cast<float*>(take(n64 * 4));
+    P.st.flags = reinterpret_cast<uint32_t*>(take(n64 * 4));
+    P.st.key = reinterpret_cast<uint32_t*>(take(n64 * 4));
+    P.st.idx = reinterpret_cast<uint32_t*>(take(n64 * 4));
+    P.st.hist = reinterpret_cast<uint32_t*>(take((static_cast<size_t>(nbins) + 64) * 4));
+    P.st.offs = reinterpret_cast<uint32_t*>(take((static_cast<size_t>(nbins) + 64) * 4));
+    P.st.cursor = reinterpret_cast<uint32_t*>(take((static_cast<size_t>(nbins) + 64) * 4));
+    const uint32_t cus = static_cast<uint32_t>(L.cu_count);
+    for (uint32_t tile_base = 0; tile_base < L.n_tiles && !rc; tile_base += tb) {
+        const uint32_t ntb = std::min(tb, L.n_tiles - tile_base);
+        P.tiles = L.d_tiles + tile_base;
+        P.n_tiles = ntb;
+        P.tile_base = tile_base;
+        for (uint32_t s0 = L.pass_begin; s0 < L.pass_end && !rc; s0 += sc) {
+            P.s0 = s0;
+            P.sc = sc;
+            P.s_end = L.pass_end;
+            P.st.n = static_cast<uint32_t>(per_tile * ntb);
+            P.st.nbins = ntb * kDirBins;
+            P.carry_in = (L.carry_in || s0 > L.pass_begin) ? 1u : 0u;
+            P.finalize = (L.finalize && s0 + sc >= L.pass_end) ? 1u : 0u;
+            rc = check(hipMemsetAsync(P.st.hist, 0, (static_cast<size_t>(P.st.nbins) + 1) * 4, st), "hipMemsetAsync(histogram)", err);
+            if (rc) break;
+            // path slots of pixels outside a clipped tile are never written by the camera stage: they must read as dead
+            rc = check(hipMemsetAsync(P.st.flags, 0, static_cast<size_t>(P.st.n) * 4, st), "hipMemsetAsync(path flags)", err);
+            if (rc) break;
+            const uint32_t units = ntb * ((ts + 1) / 2) * ((ts + 1) / 2);
+            const uint32_t cam_grid = std::min<uint32_t>((units + 3) / 4, cus * per_cu);
+            if (lds_stack) hipLaunchKernelGGL(wf_camera_kernel<true>, dim3(cam_grid), dim3(256), plds, st, P);
+            else hipLaunchKernelGGL(wf_camera_kernel<false>, dim3(cam_grid), dim3(256), 0, st, P);
+            const uint32_t flat_grid = std::min<uint32_t>((P.st.n + 255u) / 256u, cus * 16u);
+            WfParams G = P;  // bounce stage: LDS ray queue + eight traversal stacks per wave
+            G.lds_per_wave = lds_bytes_per_wave(L.scene.stack_cap);
+            const uint32_t glds = G.lds_per_wave * 4;
+            if (glds > 160 * 1024) { err = "scene too deep for the LDS traversal stacks"; rc = MP_ERR_UNSUPPORTED; break; }
+            const uint32_t gper = std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / glds));
+            for (uint32_t depth = 1; depth <= L.max_depth; depth++) {
+                P.depth = depth;
+                hipLaunchKernelGGL(wf_vertex_kernel, dim3(flat_grid), dim3(256), 0, st, P);
+                if (depth == L.max_depth) break;
+                hipLaunchKernelGGL(wf_scan_kernel, dim3(1), dim3(1024), 0, st, P);
+                hipLaunchKernelGGL(wf_scatter_kernel, dim3(flat_grid), dim3(256), 0, st, P);
+                hipLaunchKernelGGL(wf_trace_groups_kernel, dim3(cus * gper), dim3(256), glds, st, G);
+            }
+            const uint32_t px_grid = std::min<uint32_t>((ntb * ts * ts + 255u) / 256u, cus * 16u);
+            hipLaunchKernelGGL(wf_accumulate_kernel, dim3(px_grid), dim3(256), 0, st, P);
+            rc = check(hipGetLastError(), "staged path kernels launch", err);
+        }
+    }
+    (void)hipFreeAsync(ws, st);
+    return rc;
 }
 
 int launch_trace_rays(const DevScene& sc, const float* ox, const float* oy, const float* oz, const float* dx,

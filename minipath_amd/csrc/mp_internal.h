@@ -117,6 +117,7 @@ struct RenderLaunch {
 };
 
 int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err);
+int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::string& err);
 int launch_trace_rays(const DevScene& sc, const float* ox, const float* oy, const float* oz, const float* dx,
                       const float* dy, const float* dz, uint64_t n, const mp_hits_soa& hits, int cu_count, void* stream,
                       std::string& err);

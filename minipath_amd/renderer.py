@@ -25,6 +25,7 @@ class RenderSettings:
     shuffle_tiles: bool = False
     traversal: str = "packets"  # "packets": 64 camera rays per wave share one BVH walk; "groups": 8 lanes per ray
     max_depth: int = 0  # 0: reference semantics (primary ray + |d.n|).  >= 1: build-defined path extension (MP_FLAG_PATHS)
+    wavefront: bool = False  # with max_depth >= 1: staged evaluation, bounce rays sorted into packets (MP_FLAG_WAVEFRONT)
 
     def as_struct(self) -> _lib.SettingsStruct:
         if self.tile_size <= 0 or self.sample_count <= 0:
@@ -36,7 +37,8 @@ class RenderSettings:
             int(self.seed) & 0xFFFFFFFFFFFFFFFF,
             (_lib.MP_FLAG_SHUFFLE_TILES if self.shuffle_tiles else 0)
             | (_lib.MP_FLAG_TRAVERSAL_GROUPS if self.traversal == "groups" else 0)
-            | (_lib.MP_FLAG_PATHS if self.max_depth > 0 else 0),
+            | (_lib.MP_FLAG_PATHS if self.max_depth > 0 else 0)
+            | (_lib.MP_FLAG_WAVEFRONT if (self.wavefront and self.max_depth > 0) else 0),
             int(self.max_depth),
             0,
             0,

@@ -448,16 +448,18 @@ def test_atrium_deep_tree(ctx, oracle, traversal):
     _assert_hits_equal(got, exp)
 
 
+@pytest.mark.parametrize("wavefront", [False, True])
 @pytest.mark.parametrize("max_depth,spp,res,tile", [(8, 16, (256, 256), (64, 96, 128, 160)), (1, 5, (256, 256), (96, 96, 160, 160)),
-                                                    (3, 9, (250, 130), (192, 64, 250, 128)), (2, 1, (256, 256), (64, 64, 128, 128))])
-def test_path_extension_tile_bit_exact(teapot, oracle, teapot_oracle_bvh, max_depth, spp, res, tile):
+                                                    (3, 9, (250, 130), (192, 64, 250, 128)), (2, 1, (256, 256), (64, 64, 128, 128)),
+                                                    (4, 70, (256, 256), (96, 96, 128, 128))])
+def test_path_extension_tile_bit_exact(teapot, oracle, teapot_oracle_bvh, max_depth, spp, res, tile, wavefront):
     """Build-defined path extension (MP_FLAG_PATHS; no reference counterpart): GPU == oracle restatement bit for bit,
     including the number of traced ray segments.  Camera rays on the packet walk, bounce rays compacted into the LDS
     queue and traced by the 8-lane-group traversal."""
     import torch
 
     cam = mp.Camera.teapot_view()
-    st = mp.RenderSettings(64, spp, res, seed=SEED, max_depth=max_depth)
+    st = mp.RenderSettings(64, spp, res, seed=SEED, max_depth=max_depth, wavefront=wavefront)
     fr = mp.FrameRenderer(teapot, cam, st, tiles=[mp.ScreenBlock(*tile)])
     buf = fr.render()
     torch.cuda.synchronize()
@@ -487,14 +489,15 @@ def test_path_extension_atrium_and_frame(ctx, oracle):
     oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(-16.0, 4.2, 0.8), oracle.vec3(12.0, 5.5, -0.5), oracle.vec3(0, 1, 0))
     oc.f_number = 4.0
     res = (96, 64)
-    st = mp.RenderSettings(32, 6, res, seed=5, max_depth=4)
-    fr = mp.FrameRenderer(scene, scenes.atrium_camera(), st)
-    fr.render()
-    img, _ = fr.untile()
-    torch.cuda.synchronize()
     of, ou8, secs, seg = orc.render_image_paths_mt(oracle.build_sampler(oc, *res), res[0], res[1], 6, 5, 4, 32, 8)
-    assert np.array_equal(bits(img.cpu().numpy()), bits(of))
-    assert int(fr.segments.item()) == seg
+    for wavefront in (False, True):  # fused kernel, then the staged evaluation with direction-sorted bounce packets
+        st = mp.RenderSettings(32, 6, res, seed=5, max_depth=4, wavefront=wavefront)
+        fr = mp.FrameRenderer(scene, scenes.atrium_camera(), st)
+        fr.render()
+        img, _ = fr.untile()
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(img.cpu().numpy()), bits(of)), wavefront
+        assert int(fr.segments.item()) == seg
     assert seg > 3 * res[0] * res[1] * 6  # closed hall: almost every path uses all four segments
 
 
@@ -581,7 +584,7 @@ def test_sphere_object(ctx, oracle):
     assert e.value.code == 5
 
 
-@pytest.mark.parametrize("max_depth,traversal", [(0, "packets"), (0, "groups"), (5, "packets")])
+@pytest.mark.parametrize("max_depth,traversal", [(0, "packets"), (0, "groups"), (5, "packets"), (5, "wavefront")])
 def test_progressive_passes_equal_single_launch(teapot, tmp_path, max_depth, traversal):
     """MP_FLAG_ACCUMULATE: the samples of a frame drawn in several launches (ragged pass sizes, not multiples of the 8 samples in
     flight) accumulate to the bit-identical frame of one launch, also through a checkpoint file and a fresh renderer; the running
@@ -591,7 +594,9 @@ def test_progressive_passes_equal_single_launch(teapot, tmp_path, max_depth, tra
     from minipath_amd import io
 
     cam = mp.Camera.teapot_view()
-    st = mp.RenderSettings(32, 23, (96, 80), seed=SEED, traversal=traversal, max_depth=max_depth)
+    wavefront = traversal == "wavefront"
+    traversal = "packets" if wavefront else traversal
+    st = mp.RenderSettings(32, 23, (96, 80), seed=SEED, traversal=traversal, max_depth=max_depth, wavefront=wavefront)
     ref = mp.FrameRenderer(teapot, cam, st)
     ref.render()
     ref_img, ref_u8 = ref.untile()
