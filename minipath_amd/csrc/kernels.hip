@@ -976,7 +976,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 // trace kernel over the sorted stream.  Per-path RNG stream and operations are those of the fused kernel (path_vertex), every
 // ray's result is independent of its neighbours, and the per-pixel sum is taken in sample order at the end: the frame is
 // bit-identical to the fused kernel's and the oracle's (the two pipelines cross-check each other in the tests).  Measured slower
-// than the fused kernel (DESIGN.md 4.5), which therefore stays the default.
+// than the fused kernel (DESIGN.md 4.4), which therefore stays the default.
 constexpr uint32_t kDirBins = 512;  // 8 octants x 8 x 8 cells of the octahedral map of |d|
 
 struct WfState {
