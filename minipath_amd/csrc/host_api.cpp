@@ -698,60 +698,101 @@ void render_worker(mp_render* r) {
     mp_ctx* ctx = r->ctx;
     const mp_settings& st = r->settings;
     const uint32_t ts = st.tile_size;
-    const size_t per_tile = static_cast<size_t>(ts) * ts * 4;
-    // A batch is what one launch renders: enough 8x8-pixel work units to fill every CU several times over, small
-    // enough that the tile callbacks keep flowing (the reference hands out one tile per worker thread).
+    const size_t per_tile = static_cast<size_t>(ts) * ts * 4;  // floats (and u8 bytes) per tile slot
+    // A batch is what one launch renders: enough work units to fill every CU a few times over, small enough that the tile
+    // callbacks keep flowing (the reference hands out one tile per worker thread).  Two batches are in flight: while the GPU
+    // renders and quantises (color_to_image) batch k+1 and copies it to pinned host memory, this thread files batch k's rows
+    // into the image and runs its callbacks.
     const size_t units_per_tile = static_cast<size_t>((ts + 7) / 8) * ((ts + 7) / 8);
-    const size_t batch = std::max<size_t>(1, (static_cast<size_t>(ctx->cu_count) * 64 + units_per_tile - 1) / units_per_tile);
+    const size_t batch = std::max<size_t>(1, (static_cast<size_t>(ctx->cu_count) * 16 + units_per_tile - 1) / units_per_tile);
     auto set_error = [&](int code, const std::string& msg) {
         r->status = code;
         r->error = msg;
     };
-    hipStream_t stream = nullptr;
-    float* d_out = nullptr;
-    mp_block* d_tiles = nullptr;
-    std::vector<float> host(batch * per_tile);
+    struct Slot {
+        hipStream_t stream = nullptr;
+        float* d_f32 = nullptr;
+        uint8_t* d_u8 = nullptr;
+        mp_block* d_tiles = nullptr;
+        float* h_f32 = nullptr;    // pinned
+        uint8_t* h_u8 = nullptr;   // pinned
+        size_t first = 0, n = 0;   // tiles of the batch in flight
+        bool busy = false;
+    } slot[2];
     hipError_t e = hipSetDevice(ctx->device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_out), batch * per_tile * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_tiles), batch * sizeof(mp_block));
+    for (Slot& s : slot) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s.d_f32), batch * per_tile * 4);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s.d_u8), batch * per_tile);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s.d_tiles), batch * sizeof(mp_block));
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s.h_f32), batch * per_tile * 4, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s.h_u8), batch * per_tile, hipHostMallocDefault);
+    }
     if (e != hipSuccess) set_error(MP_ERR_HIP, std::string("render worker setup: ") + hipGetErrorString(e));
 
     const size_t total = r->tiles.size();
-    while (r->status == MP_OK) {
-        // get_next_tile (machinery.rs:205-208): abort() stores `len` so no new tiles are handed out
-        size_t first = r->next_tile.fetch_add(batch, std::memory_order_acq_rel);
-        if (first >= total) break;
-        size_t n = std::min(batch, total - first);
-        const mp_block* t = &r->tiles[first];
-        if (r->started)
-            for (size_t i = 0; i < n; i++) r->started(r->user, t[i]);  // machinery.rs:75
-        e = hipMemcpyAsync(d_tiles, t, n * sizeof(mp_block), hipMemcpyHostToDevice, stream);
-        if (e != hipSuccess) { set_error(MP_ERR_HIP, std::string("hipMemcpyAsync(tiles): ") + hipGetErrorString(e)); break; }
-        int rc = render_tiles_device(ctx, r->scene, r->sampler, st, d_tiles, n, d_out, stream);
-        if (rc) { set_error(rc, mp_last_error()); break; }
-        e = hipMemcpyAsync(host.data(), d_out, n * per_tile * 4, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) { set_error(MP_ERR_HIP, std::string("tile readback: ") + hipGetErrorString(e)); break; }
-        for (size_t i = 0; i < n; i++) {
-            const mp_block& b = t[i];
+    // waits for the slot's batch and files it into the image (machinery.rs:78-99)
+    auto retire = [&](Slot& s) {
+        if (!s.busy) return;
+        s.busy = false;
+        hipError_t se = hipStreamSynchronize(s.stream);
+        if (se != hipSuccess) { set_error(MP_ERR_HIP, std::string("tile readback: ") + hipGetErrorString(se)); return; }
+        for (size_t i = 0; i < s.n; i++) {
+            const mp_block& b = r->tiles[s.first + i];
+            const size_t w = b.max_x - b.min_x;
             {
                 std::lock_guard<std::mutex> lk(r->image_mu);  // image.lock().copy_from(..) machinery.rs:78-89
-                for (uint32_t y = b.min_y; y < b.max_y; y++)
-                    for (uint32_t x = b.min_x; x < b.max_x; x++) {
-                        const float* p = &host[i * per_tile + (static_cast<size_t>(y - b.min_y) * ts + (x - b.min_x)) * 4];
-                        size_t o = (static_cast<size_t>(y) * st.width + x) * 4;
-                        std::memcpy(&r->image_f32[o], p, 16);
-                        for (int k = 0; k < 4; k++) r->image_u8[o + k] = to_u8(p[k]);
-                    }
+                for (uint32_t y = b.min_y; y < b.max_y; y++) {
+                    const size_t src = i * per_tile + static_cast<size_t>(y - b.min_y) * ts * 4;
+                    const size_t dst = (static_cast<size_t>(y) * st.width + b.min_x) * 4;
+                    std::memcpy(&r->image_f32[dst], s.h_f32 + src, w * 16);
+                    std::memcpy(&r->image_u8[dst], s.h_u8 + src, w * 4);
+                }
             }
             size_t done = r->done_tiles.fetch_add(1, std::memory_order_acq_rel) + 1;
             if (r->finished) r->finished(r->user, b, mp_progress{done, total});  // machinery.rs:93-99
         }
+    };
+    int cur = 0;
+    while (r->status == MP_OK) {
+        // get_next_tile (machinery.rs:205-208): abort() stores `len` so no new tiles are handed out
+        size_t first = r->next_tile.fetch_add(batch, std::memory_order_acq_rel);
+        if (first >= total) break;
+        Slot& s = slot[cur];
+        retire(s);  // the batch issued two rounds ago
+        if (r->status != MP_OK) break;
+        s.first = first;
+        s.n = std::min(batch, total - first);
+        const mp_block* t = &r->tiles[first];
+        if (r->started)
+            for (size_t i = 0; i < s.n; i++) r->started(r->user, t[i]);  // machinery.rs:75
+        e = hipMemcpyAsync(s.d_tiles, t, s.n * sizeof(mp_block), hipMemcpyHostToDevice, s.stream);
+        if (e != hipSuccess) { set_error(MP_ERR_HIP, std::string("hipMemcpyAsync(tiles): ") + hipGetErrorString(e)); break; }
+        int rc = render_tiles_device(ctx, r->scene, r->sampler, st, s.d_tiles, s.n, s.d_f32, s.stream);
+        std::string err;
+        if (!rc) {
+            rc = launch_quantise(s.d_f32, s.d_u8, static_cast<uint64_t>(s.n) * ts * ts, s.stream, err);
+            if (rc) fail(rc, err);
+        }
+        if (rc) { set_error(rc, mp_last_error()); break; }
+        e = hipMemcpyAsync(s.h_f32, s.d_f32, s.n * per_tile * 4, hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.h_u8, s.d_u8, s.n * per_tile, hipMemcpyDeviceToHost, s.stream);
+        if (e != hipSuccess) { set_error(MP_ERR_HIP, std::string("tile readback: ") + hipGetErrorString(e)); break; }
+        s.busy = true;
+        cur ^= 1;
     }
-    if (d_out) (void)hipFree(d_out);
-    if (d_tiles) (void)hipFree(d_tiles);
-    if (stream) (void)hipStreamDestroy(stream);
+    // drain in issue order: slot[cur] holds the older batch
+    retire(slot[cur]);
+    retire(slot[cur ^ 1]);
+    for (Slot& s : slot) {
+        if (s.stream) (void)hipStreamSynchronize(s.stream);
+        if (s.d_f32) (void)hipFree(s.d_f32);
+        if (s.d_u8) (void)hipFree(s.d_u8);
+        if (s.d_tiles) (void)hipFree(s.d_tiles);
+        if (s.h_f32) (void)hipHostFree(s.h_f32);
+        if (s.h_u8) (void)hipHostFree(s.h_u8);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
     {
         std::lock_guard<std::mutex> lk(r->end_mu);  // machinery.rs:107-113
         r->elapsed = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - r->start);

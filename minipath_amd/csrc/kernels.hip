@@ -1354,6 +1354,16 @@ __global__ __launch_bounds__(256) void untile_kernel(uint32_t width, uint32_t he
     }
 }
 
+// color_to_image (worker.rs:69-76) over a tile-major pixel buffer: RGBA f32 -> RGBA u8, same layout (the render() worker reads
+// both back and only copies rows on the host).
+__global__ __launch_bounds__(256) void quantise_kernel(const float* src, uint8_t* dst, uint64_t n_pixels) {
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n_pixels;
+         i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i * 4);
+        *reinterpret_cast<uchar4*>(dst + i * 4) = make_uchar4(to_u8(v.x), to_u8(v.y), to_u8(v.z), to_u8(v.w));
+    }
+}
+
 __global__ void set_u64_kernel(unsigned long long* p, unsigned long long v) { *p = v; }
 
 // UniformFloat::new_inclusive(low, high).scale (rand 0.9): (high-low)/max_rand, reduced by ulps until
@@ -1608,6 +1618,13 @@ int launch_untile(uint32_t width, uint32_t height, uint32_t tile_size, const mp_
     hipLaunchKernelGGL(untile_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), width, height, tile_size,
                        d_tiles, n_tiles, d_tiles_f32, d_image_f32, d_image_u8);
     return check(hipGetLastError(), "untile_kernel launch", err);
+}
+
+int launch_quantise(const float* d_rgba_f32, uint8_t* d_rgba_u8, uint64_t n_pixels, void* stream, std::string& err) {
+    if (n_pixels == 0) return MP_OK;
+    const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n_pixels + 255) / 256, 8192));
+    hipLaunchKernelGGL(quantise_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), d_rgba_f32, d_rgba_u8, n_pixels);
+    return check(hipGetLastError(), "quantise_kernel launch", err);
 }
 
 }  // namespace mp

@@ -128,6 +128,8 @@ int launch_generate_rays(const mp_camera_sampler& s, uint32_t width, uint32_t sp
 int launch_untile(uint32_t width, uint32_t height, uint32_t tile_size, const mp_block* d_tiles, uint32_t n_tiles,
                   const float* d_tiles_f32, float* d_image_f32, uint8_t* d_image_u8, void* stream, std::string& err);
 
+int launch_quantise(const float* d_rgba_f32, uint8_t* d_rgba_u8, uint64_t n_pixels, void* stream, std::string& err);
+
 // camera / tiles (host_camera.cpp)
 void camera_default(mp_camera& c);
 void camera_look_at(mp_camera& c, const float eye[3], const float at[3], const float up[3]);

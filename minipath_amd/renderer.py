@@ -131,7 +131,9 @@ def render(
         if finished_tile_callback:
             finished_tile_callback(ScreenBlock(*blk.as_tuple()), RenderProgressSnapshot(prog.finished, prog.total))
 
-    cb1, cb2 = _lib.STARTED_CB(_started), _lib.FINISHED_CB(_finished)
+    # NULL when the caller passes no callback: the worker thread then never enters Python
+    cb1 = _lib.STARTED_CB(_started) if started_tile_callback else _lib.STARTED_CB()
+    cb2 = _lib.FINISHED_CB(_finished) if finished_tile_callback else _lib.FINISHED_CB()
     h = C.c_void_p()
     cam = camera._struct()
     st = settings.as_struct()
