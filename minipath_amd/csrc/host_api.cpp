@@ -70,6 +70,24 @@ struct mp_ctx {
         unsigned char* d_buf = nullptr;  // tiles, then order
         uint64_t last_use = 0;
     };
+    // Buffers of the render() worker (stream, device tile-major f32/u8 + tile list, pinned host mirrors), kept between calls:
+    // creating and freeing them costs several milliseconds per render() otherwise.
+    struct WorkerSlot {
+        hipStream_t stream = nullptr;
+        float* d_f32 = nullptr;
+        uint8_t* d_u8 = nullptr;
+        mp_block* d_tiles = nullptr;
+        float* h_f32 = nullptr;   // pinned
+        uint8_t* h_u8 = nullptr;  // pinned
+        size_t tiles = 0, per_tile = 0;  // capacity: `tiles` tile slots of per_tile floats
+        size_t first = 0, n = 0;  // batch in flight
+        bool busy = false;
+    };
+    std::mutex slot_mutex;
+    std::vector<WorkerSlot> free_slots;
+    int acquire_slot(size_t tiles, size_t per_tile, WorkerSlot& out);
+    void release_slot(const WorkerSlot& s);
+    static void destroy_slot(WorkerSlot& s);
     static constexpr size_t kTileLists = 32;
     std::mutex tile_mutex;
     std::vector<TileList> tile_lists;
@@ -142,6 +160,56 @@ int mp_ctx::device_tiles(const mp_block* tiles, size_t n, const uint32_t* order,
     *d_tiles = reinterpret_cast<const mp_block*>(hit->d_buf);
     if (d_order) *d_order = order ? reinterpret_cast<const uint32_t*>(hit->d_buf + tb) : nullptr;
     return MP_OK;
+}
+
+void mp_ctx::destroy_slot(WorkerSlot& s) {
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    if (s.d_f32) (void)hipFree(s.d_f32);
+    if (s.d_u8) (void)hipFree(s.d_u8);
+    if (s.d_tiles) (void)hipFree(s.d_tiles);
+    if (s.h_f32) (void)hipHostFree(s.h_f32);
+    if (s.h_u8) (void)hipHostFree(s.h_u8);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    s = WorkerSlot{};
+}
+
+int mp_ctx::acquire_slot(size_t tiles, size_t per_tile, WorkerSlot& out) {
+    {
+        std::lock_guard<std::mutex> lock(slot_mutex);
+        for (size_t i = 0; i < free_slots.size(); i++)
+            if (free_slots[i].tiles * free_slots[i].per_tile >= tiles * per_tile && free_slots[i].tiles >= tiles) {
+                out = free_slots[i];
+                free_slots.erase(free_slots.begin() + static_cast<std::ptrdiff_t>(i));
+                out.busy = false;
+                return MP_OK;
+            }
+    }
+    WorkerSlot s;
+    s.tiles = tiles;
+    s.per_tile = per_tile;
+    hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s.d_f32), tiles * per_tile * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s.d_u8), tiles * per_tile);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s.d_tiles), tiles * sizeof(mp_block));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s.h_f32), tiles * per_tile * 4, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s.h_u8), tiles * per_tile, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        destroy_slot(s);
+        return hip_fail(e, "render worker buffers");
+    }
+    out = s;
+    return MP_OK;
+}
+
+void mp_ctx::release_slot(const WorkerSlot& s) {
+    if (!s.stream) return;
+    std::lock_guard<std::mutex> lock(slot_mutex);
+    if (free_slots.size() < 8) {
+        free_slots.push_back(s);
+    } else {
+        WorkerSlot d = s;
+        destroy_slot(d);
+    }
 }
 
 namespace {
@@ -387,6 +455,7 @@ void mp_ctx_destroy(mp_ctx* ctx) {
     DeviceGuard g(ctx->device);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     for (auto& e : ctx->tile_lists) (void)hipFree(e.d_buf);
+    for (auto& sl : ctx->free_slots) mp_ctx::destroy_slot(sl);
     delete ctx;
 }
 
@@ -709,26 +778,15 @@ void render_worker(mp_render* r) {
         r->status = code;
         r->error = msg;
     };
-    struct Slot {
-        hipStream_t stream = nullptr;
-        float* d_f32 = nullptr;
-        uint8_t* d_u8 = nullptr;
-        mp_block* d_tiles = nullptr;
-        float* h_f32 = nullptr;    // pinned
-        uint8_t* h_u8 = nullptr;   // pinned
-        size_t first = 0, n = 0;   // tiles of the batch in flight
-        bool busy = false;
-    } slot[2];
+    using Slot = mp_ctx::WorkerSlot;
+    Slot slot[2];
     hipError_t e = hipSetDevice(ctx->device);
-    for (Slot& s : slot) {
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s.d_f32), batch * per_tile * 4);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s.d_u8), batch * per_tile);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s.d_tiles), batch * sizeof(mp_block));
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s.h_f32), batch * per_tile * 4, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s.h_u8), batch * per_tile, hipHostMallocDefault);
-    }
     if (e != hipSuccess) set_error(MP_ERR_HIP, std::string("render worker setup: ") + hipGetErrorString(e));
+    for (Slot& s : slot)
+        if (r->status == MP_OK) {
+            int rc = ctx->acquire_slot(batch, per_tile, s);
+            if (rc) set_error(rc, mp_last_error());
+        }
 
     const size_t total = r->tiles.size();
     // waits for the slot's batch and files it into the image (machinery.rs:78-99)
@@ -786,12 +844,8 @@ void render_worker(mp_render* r) {
     retire(slot[cur ^ 1]);
     for (Slot& s : slot) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
-        if (s.d_f32) (void)hipFree(s.d_f32);
-        if (s.d_u8) (void)hipFree(s.d_u8);
-        if (s.d_tiles) (void)hipFree(s.d_tiles);
-        if (s.h_f32) (void)hipHostFree(s.h_f32);
-        if (s.h_u8) (void)hipHostFree(s.h_u8);
-        if (s.stream) (void)hipStreamDestroy(s.stream);
+        s.busy = false;
+        ctx->release_slot(s);
     }
     {
         std::lock_guard<std::mutex> lk(r->end_mu);  // machinery.rs:107-113
