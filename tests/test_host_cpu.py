@@ -42,6 +42,43 @@ def _assert_same_bvh(prod: mp.TriangleBvh, orc):
     assert np.array_equal(vt.view(np.uint32), orc.vertex_tex().view(np.uint32))
 
 
+def test_ctypes_mirror_matches_the_header_layout(tmp_path):
+    """The header is the contract: sizes and member offsets of every public struct, as the C compiler sees them, must equal the
+    ctypes mirror the Python host side (and the tests) marshal through."""
+    import ctypes as C
+    import subprocess
+
+    from minipath_amd import _lib
+
+    structs = {
+        "mp_block": (_lib.Block, ["min_x", "min_y", "max_x", "max_y"]),
+        "mp_camera": (_lib.CameraStruct, None),
+        "mp_camera_sampler": (_lib.SamplerStruct, None),
+        "mp_settings": (_lib.SettingsStruct, None),
+        "mp_progress": (_lib.Progress, None),
+        "mp_scene_info": (_lib.SceneInfo, None),
+        "mp_hits_soa": (_lib.HitsSoA, None),
+        "mp_launch_extras": (_lib.LaunchExtras, None),
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "minipath_hip.h"', "int main(void) {"]
+    for cname, (cls, _) in structs.items():
+        lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ftype in cls._fields_:
+            lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-std=c11", "-I", inc, str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for cname, (cls, _) in structs.items():
+        assert got[(cname, "size")] == C.sizeof(cls), cname
+        for fname, _ftype in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
 def test_builder_teapot_matches_oracle(oracle, teapot_oracle_bvh):
     """building.rs (all): OBJ load + dedupe + recursive build, byte-identical reference-layout arrays."""
     prod = mp.TriangleBvh.with_obj(TEAPOT)
