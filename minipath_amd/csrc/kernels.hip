@@ -175,7 +175,6 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
     int slot = -1, sp = 0, head = 0;
     uint32_t pk = 0, pk_end = 0, seq = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0;
-    bool slow = false;  // infinite inverse component: 0 * inf = NaN can arise in the slab test (aabb.rs:262-267)
     // Lane li fetches child li / triangle li as whole 16-byte words from the AoS copies (two loads per node, three per packet)
     const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes_aos);
     const float4* __restrict__ tris4 = reinterpret_cast<const float4*>(sc.tris_aos);
@@ -216,7 +215,6 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
                 dx = q[3 * 64 + mine]; dy = q[4 * 64 + mine]; dz = q[5 * 64 + mine];
                 // inv_direction as Ray::new has it (geometry/mod.rs:49-53), recomputed rather than queued: 3 LDS rows less per wave
                 ix = (dx == 0.0f) ? INFINITY : 1.0f / dx; iy = (dy == 0.0f) ? INFINITY : 1.0f / dy; iz = (dz == 0.0f) ? INFINITY : 1.0f / dz;
-                slow = fabsf(ix) == INFINITY || fabsf(iy) == INFINITY || fabsf(iz) == INFINITY;
                 best_t = FLT_MAX; tl = FLT_MAX; ul = 0; vl = 0; pkl = kNoPrim; seql = 0; seq = 0;
                 pk = pk_end = 0;
                 sp = 1;
@@ -241,10 +239,10 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
                     // aabb.rs:254-284
                     float ax = (c0.x - ox) * ix, ay = (c0.y - oy) * iy, az = (c0.z - oz) * iz;
                     float cx = (c0.w - ox) * ix, cy = (c1.x - oy) * iy, cz = (c1.y - oz) * iz;
-                    if (__ballot(slow) != 0) {
-                        ax = (ax != ax) ? -INFINITY : ax; ay = (ay != ay) ? -INFINITY : ay; az = (az != az) ? -INFINITY : az;
-                        cx = (cx != cx) ? INFINITY : cx; cy = (cy != cy) ? INFINITY : cy; cz = (cz != cz) ? INFINITY : cz;
-                    }
+                    // NaN (0 * inf) -> -inf on the min side, +inf on the max side (aabb.rs:262-267): maxNum / minNum return the
+                    // other operand for a NaN and the value itself otherwise, one instruction each and no branch
+                    ax = fmaxf(ax, -INFINITY); ay = fmaxf(ay, -INFINITY); az = fmaxf(az, -INFINITY);
+                    cx = fminf(cx, INFINITY); cy = fminf(cy, INFINITY); cz = fminf(cz, INFINITY);
                     const float t1 = fmaxf(fmaxf(fminf(ax, cx), 0.0f), fmaxf(fminf(ay, cy), fminf(az, cz)));
                     const float t2 = fminf(fminf(fmaxf(ax, cx), best_t), fminf(fmaxf(ay, cy), fmaxf(az, cz)));
                     bool ok = (t1 <= t2) && (child != MP_LINK_NULL);  // Null links are skipped at pop in the reference (:49)
@@ -516,9 +514,9 @@ __device__ __forceinline__ void slab(float bnx, float bny, float bnz, float bxx,
     // aabb.rs:254-284
     float ax = (bnx - r.ox) * r.ix, ay = (bny - r.oy) * r.iy, az = (bnz - r.oz) * r.iz;
     float cx = (bxx - r.ox) * r.ix, cy = (bxy - r.oy) * r.iy, cz = (bxz - r.oz) * r.iz;
-    if (PATCH_NAN) {  // only rays with an infinite inverse direction component can produce 0*inf (see trace_wave)
-        ax = (ax != ax) ? -INFINITY : ax; ay = (ay != ay) ? -INFINITY : ay; az = (az != az) ? -INFINITY : az;
-        cx = (cx != cx) ? INFINITY : cx; cy = (cy != cy) ? INFINITY : cy; cz = (cz != cz) ? INFINITY : cz;
+    if (PATCH_NAN) {  // only rays with an infinite inverse direction component can produce 0*inf; maxNum/minNum drop a NaN operand
+        ax = fmaxf(ax, -INFINITY); ay = fmaxf(ay, -INFINITY); az = fmaxf(az, -INFINITY);
+        cx = fminf(cx, INFINITY); cy = fminf(cy, INFINITY); cz = fminf(cz, INFINITY);
     }
     float lox, loy, loz, hix, hiy, hiz;
     if (OCT >= 0) {

@@ -703,6 +703,28 @@ def test_profile_guided_tile_order_same_image(teapot, max_depth):
         fr.render()
 
 
+def test_tile_list_cache_eviction(teapot, oracle, teapot_oracle_bvh):
+    """The context keeps device copies of the tile lists callers pass (32 entries, least recently used evicted): more distinct
+    lists than that, re-used afterwards, still render their own tiles."""
+    import torch
+
+    res, spp = (512, 512), 2
+    st = mp.RenderSettings(32, spp, res, seed=SEED)
+    cam = mp.Camera.teapot_view()
+    smp = oracle.build_sampler(oracle.teapot_camera(), *res)
+    lists = [[mp.ScreenBlock(32 * (i % 16), 32 * (i // 16) + 128, 32 * (i % 16) + 32, 32 * (i // 16) + 160)] for i in range(40)]
+    renderers = [mp.FrameRenderer(teapot, cam, st, tiles=tl) for tl in lists]
+    for rounds in range(2):  # second round: the first eight lists were evicted in the first
+        for fr in renderers:
+            fr.tile_buf.zero_()
+            fr.render()
+        torch.cuda.synchronize()
+        for i in (0, 7, 21, 39):
+            t = lists[i][0]
+            want, _ = teapot_oracle_bvh.render_tile(smp, res[0], res[1], spp, SEED, t.min_x, t.min_y, t.max_x, t.max_y)
+            assert np.array_equal(bits(renderers[i].tile_buf[0].cpu().numpy()), bits(want)), (rounds, i)
+
+
 @pytest.mark.gpu
 def test_bench_two_rank_rehearsal():
     """bench.py's N > 1 path (shard plan, gather to rank 0, reassembly, max-over-ranks timing) with two ranks sharing this
