@@ -725,6 +725,18 @@ def test_tile_list_cache_eviction(teapot, oracle, teapot_oracle_bvh):
             assert np.array_equal(bits(renderers[i].tile_buf[0].cpu().numpy()), bits(want)), (rounds, i)
 
 
+def test_differential_fuzz(ctx):
+    """tools/fuzz_gpu.py, bounded: random scenes / cameras (incl. axis-aligned views with zero direction components) / sizes /
+    sample counts / kernels (packets, groups, fused paths, staged paths) / work-unit sizes / stack splits / progressive splits,
+    every frame bit-identical to the oracle.  (Round 1 ran 1 650 such cases with no mismatch.)"""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(60, 20261005, ctx) == 0
+
+
 @pytest.mark.gpu
 def test_bench_two_rank_rehearsal():
     """bench.py's N > 1 path (shard plan, gather to rank 0, reassembly, max-over-ranks timing) with two ranks sharing this

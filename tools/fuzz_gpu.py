@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the GPU render paths against the oracle: random small scenes, cameras (incl. axis-aligned views that
+produce zero direction components), resolutions, tile sizes, sample counts, kernels (packets / groups / fused paths / staged paths),
+work-unit sizes, progressive splits.  Every frame must match the oracle bit for bit.  usage: fuzz_gpu.py [cases] [seed]"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import minipath_amd as mp
+from oracle import pyoracle as po
+from tests import meshes
+
+def bits(a): return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+def run(cases, seed, ctx=None):
+    """Returns the number of mismatching cases."""
+    rng = np.random.default_rng(seed)
+    ctx = ctx if ctx is not None else mp.Context(0)
+    scenes = {}
+    for name in ("soup_300", "grid_40", "sphere_24", "flat_plane", "soup_5000"):
+        pos, nrm, tex, tri = meshes.make(name)
+        scenes[name] = (mp.Scene(mp.TriangleBvh.build(pos, nrm, tex, tri, ctx)), po.Bvh.build(pos, nrm, tex, tri))
+    bad = 0
+    for case in range(cases):
+        name = list(scenes)[int(rng.integers(len(scenes)))]
+        scene, ob = scenes[name]
+        w, h = int(rng.integers(17, 150)), int(rng.integers(9, 120))
+        ts = int(rng.choice([8, 16, 24, 32, 64]))
+        spp = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 33, 70]))
+        seed = int(rng.integers(1 << 40))
+        if rng.random() < 0.3:   # axis-aligned view: exact zero direction components at the image centre lines
+            axis = int(rng.integers(3)); eye = np.zeros(3); eye[axis] = float(rng.choice([-6.0, 6.0])); at = np.zeros(3)
+            up = np.zeros(3); up[(axis + 1) % 3] = 1.0
+        else:
+            eye = rng.normal(size=3) * 4.0 + np.array([0, 1.0, 0]); at = rng.normal(size=3) * 0.5; up = np.array([0.0, 1.0, 0.0])
+        fnum = float(rng.choice([1.4, 4.8, 16.0, 1e9]))
+        cam = mp.Camera.default().look_at(tuple(eye), tuple(at), tuple(up)).f_number(fnum)
+        oc = po.Camera(); po.lib().mpo_camera_default(C.byref(oc)); po.lib().mpo_camera_look_at(C.byref(oc), po.vec3(*eye), po.vec3(*at), po.vec3(*up)); oc.f_number = fnum
+        smp = po.build_sampler(oc, w, h)
+        mode = str(rng.choice(["packets", "groups", "paths", "staged"]))
+        depth = int(rng.integers(1, 6)) if mode in ("paths", "staged") else 0
+        s_opt = int(rng.choice([0, 0, 1, 4, 8, 16, 32, 64]))
+        ctx.set_option("packet_samples_in_flight", s_opt)
+        ctx.set_option("packet_stack_registers", int(rng.choice([64, 64, 3, 9])))
+        st = mp.RenderSettings(ts, spp, (w, h), seed=seed, traversal="groups" if mode == "groups" else "packets", max_depth=depth, wavefront=(mode == "staged"))
+        fr = mp.FrameRenderer(scene, cam, st)
+        if rng.random() < 0.4 and spp > 1:   # progressive split
+            cut = int(rng.integers(1, spp)); nxt = fr.render_pass(0, cut); fr.render_pass(nxt)
+        else:
+            fr.render()
+        img, u8 = fr.untile()
+        torch.cuda.synchronize()
+        if depth:
+            of, ou8, _, seg = ob.render_image_paths_mt(smp, w, h, spp, seed, depth, ts, 8)
+        else:
+            of, ou8, _, seg, _ = ob.render_image_mt(smp, w, h, spp, seed, ts, 8)
+        ok = np.array_equal(bits(img.cpu().numpy()), bits(of)) and np.array_equal(u8.cpu().numpy(), ou8)
+        if not ok:
+            bad += 1
+            print(f"MISMATCH case {case}: {name} {w}x{h} ts{ts} spp{spp} seed{seed} mode {mode} depth {depth} S{s_opt} eye{eye} at{at} f{fnum}: "
+                  f"{int(np.sum(bits(img.cpu().numpy()) != bits(of)))} f32 values differ")
+    ctx.set_option("packet_samples_in_flight", 0)
+    ctx.set_option("packet_stack_registers", 64)
+    return bad
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{n} cases, {bad} mismatching")
+    sys.exit(1 if bad else 0)
