@@ -780,7 +780,7 @@ __device__ __forceinline__ void add_samples_in_order(float& acc, float c, int la
 // Fused tile render on ray packets.  A wave owns a block of 64/S pixels and shoots S consecutive samples of each
 // pixel per pass (lane = pixel*S + sub-sample): all 64 rays of a pass are neighbours on the film, so the packet stays
 // coherent, while the work unit (block x all samples) shrinks with S, which evens out the load.  pixel_sum is
-// accumulated strictly in sample order (worker.rs:41-43) by the lane with sub-sample 0.
+// accumulated strictly in sample order (worker.rs:41-43), redundantly by every lane of the pixel (add_samples_in_order).
 // WPE = waves per SIMD the register allocation is held to: 8 (64 VGPRs) hides the scalar-cache misses of scenes that
 // outgrow it, 7 (72 VGPRs) schedules slightly better when the scene stays cache resident (profiles/r01_notes.md).
 template <int S, bool LDS_STACK, int WPE>
@@ -1439,8 +1439,8 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);
         return check(hipGetLastError(), "render_tiles_kernel launch", err);
     }
-    // samples of one pixel in flight per pass: 8 keeps the 64 rays of a pass within a 4x2 pixel footprint and makes
-    // the work units 8x smaller than a whole 8x8 block (measured best on MI355X: profiles/r01_notes.md)
+    // samples of one pixel in flight per pass: 16 = one DPP row per pixel (ordered sums by row_newbcast), a 2x2 pixel footprint per
+    // wave and 4-pixel work units (measured best on MI355X for full frames: profiles/r01_notes.md)
     const uint32_t nspp = L.pass_end - L.pass_begin;  // samples per pixel in this launch
     int S = nspp >= 16 ? 16 : nspp >= 8 ? 8 : nspp >= 4 ? 4 : nspp >= 2 ? 2 : 1;
     // small launches (a rank's shard of a multi-GPU frame): 2-pixel units, so that the tail of the launch is half as long
