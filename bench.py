@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16, help="upper bound on cpu_baseline worker threads")
     ap.add_argument("--traversal", default="packets", choices=["packets", "groups"])
     ap.add_argument("--depth", type=int, default=0, help="0 = reference semantics (default); N >= 1 = build-defined path extension with at most N segments")
+    ap.add_argument("--balance", default="static", choices=["static", "lpt"],
+                    help="N > 1: 'lpt' re-partitions the tiles over the ranks by the cost the warmup frames measured (opt-in)")
     ap.add_argument("--wavefront", action="store_true", help="with --depth N: staged evaluation, bounce rays sorted into packets")
     ap.add_argument("--no-extension", action="store_true", help="skip the extra 'paths_depth8' measurement")
     ap.add_argument("--check", action="store_true", help="compare a few tiles of the GPU frame with the oracle")
@@ -166,7 +168,9 @@ def main():
     for _ in range(args.warmup):
         step(False)
     frame.flush()
-    if args.warmup > 0:
+    if args.warmup > 0 and args.balance == "lpt" and world > 1:
+        frame.repartition_by_cost()  # cost-balanced shards, expensive tiles first (collective)
+    elif args.warmup > 0:
         frame.rebalance()  # hand the tiles the warmup frames found expensive to the waves first (same image, shorter tail)
     barrier()
     t0 = time.perf_counter()

@@ -77,6 +77,7 @@ class DistributedFrame:
 
         w, h = settings.resolution
         self.rank, self.world, self.settings = rank, world, settings
+        self._camera = camera
         self.all_tiles = list(tiles) if tiles is not None else tile_ordering(ScreenBlock(0, 0, w, h), settings.tile_size)
         self.plan = plan_shards(self.all_tiles, world)
         ts = settings.tile_size
@@ -110,6 +111,55 @@ class DistributedFrame:
         """Profile-guided tile hand-out for this rank's following launches (FrameRenderer.rebalance): purely local, the shard
         layout and the gather do not change."""
         return self.renderer.rebalance()
+
+    def repartition_by_cost(self):
+        """Cost-balanced partition for the following frames (opt-in; bench.py --balance lpt): every rank contributes the shader
+        cycles its launches measured per tile (FrameRenderer.tile_cost), all ranks compute the SAME longest-processing-time
+        assignment from the all-gathered costs (tiles by descending cost, each to the least loaded rank, ties to the lower
+        rank / tile index), and rebuild their shard: tile list (already expensive-first, so no hand-out permutation is needed),
+        shard and gather buffers, un-tile order.  The image does not depend on the partition.  Collective: call on every rank,
+        with no frame in flight (after flush())."""
+        import torch
+        import torch.distributed as dist
+
+        from . import _lib
+        from .renderer import FrameRenderer
+
+        assert self._pending is None, "flush() before repartitioning"
+        world, per = self.world, max(self.plan.per_rank, 1)
+        mine = self.plan.shards[self.rank]
+        dev = self.renderer.device
+        local = torch.zeros(per, dtype=torch.int64, device=dev)
+        local[: len(mine)] = self.renderer.tile_cost[: len(mine)]
+        if world > 1:
+            gathered = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+        else:
+            gathered = [local]
+        costs = [g.cpu().tolist() for g in gathered]
+        index = {t: i for i, t in enumerate(self.all_tiles)}
+        cost = [0] * len(self.all_tiles)
+        for r, shard in enumerate(self.plan.shards):
+            for k, t in enumerate(shard):
+                cost[index[t]] = int(costs[r][k])
+        order = sorted(range(len(cost)), key=lambda i: (-cost[i], i))
+        loads, shards = [0] * world, [[] for _ in range(world)]
+        for i in order:
+            r = min(range(world), key=lambda q: (loads[q], q))
+            shards[r].append(self.all_tiles[i])
+            loads[r] += cost[i]
+        self.plan = ShardPlan(world, max(len(s) for s in shards), tuple(tuple(s) for s in shards))
+        ts = self.settings.tile_size
+        self._shards = [torch.zeros((max(self.plan.per_rank, 1), ts, ts, 4), dtype=torch.float32, device=dev) for _ in range(len(self._shards))]
+        old = self.renderer
+        self.renderer = FrameRenderer(old.scene, self._camera, self.settings, tiles=self.plan.shards[self.rank], tile_buf=self._shards[0])
+        self._frame = 0
+        if self.rank == 0 and world > 1:
+            self._gather_buf = torch.zeros((world * self.plan.per_rank, ts, ts, 4), dtype=torch.float32, device=dev)
+            self._gather_views = [self._gather_buf[r * self.plan.per_rank:(r + 1) * self.plan.per_rank] for r in range(world)]
+            o = self.plan.gather_order
+            self._order = (o, (_lib.Block * max(len(o), 1))(*[t.as_struct() for t in o]))
+        return loads
 
     def _complete(self):
         """Wait (on the current stream) for the gather in flight and un-tile its frame on rank 0."""

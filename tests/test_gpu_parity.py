@@ -738,7 +738,8 @@ def test_differential_fuzz(ctx):
 
 
 @pytest.mark.gpu
-def test_bench_two_rank_rehearsal():
+@pytest.mark.parametrize("balance", ["static", "lpt"])
+def test_bench_two_rank_rehearsal(balance):
     """bench.py's N > 1 path (shard plan, gather to rank 0, reassembly, max-over-ranks timing) with two ranks sharing this
     box's GPU over gloo (MP_BENCH_REHEARSAL=1: RCCL refuses duplicate devices); the gathered frame is checked against the
     oracle inside bench.py (--check)."""
@@ -749,8 +750,8 @@ def test_bench_two_rank_rehearsal():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MP_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--width", "320", "--height", "200", "--spp", "16", "--no-cpu-baseline", "--check"]
+           "--master-port", "29533" if balance == "static" else "29534", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", "320", "--height", "200", "--spp", "16", "--no-cpu-baseline", "--check", "--balance", balance]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
