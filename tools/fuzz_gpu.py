@@ -22,6 +22,8 @@ def run(cases, seed, ctx=None):
         scenes[name] = (mp.Scene(mp.TriangleBvh.build(pos, nrm, tex, tri, ctx)), po.Bvh.build(pos, nrm, tex, tri))
     bad = 0
     for case in range(cases):
+        if case and case % 500 == 0:
+            print(f"... {case} cases, {bad} mismatching so far", flush=True)
         name = list(scenes)[int(rng.integers(len(scenes)))]
         scene, ob = scenes[name]
         w, h = int(rng.integers(17, 150)), int(rng.integers(9, 120))
