@@ -8,8 +8,9 @@
  *
  * Conventions
  *   - plain C types, pointers and sizes only; no C++/torch types cross the boundary;
- *   - every function returns an int status (MP_OK == 0); no exception or abort crosses the ABI; the message of
- *     the last failure on the calling thread is mp_last_error();
+ *   - every function returns an int status (MP_OK == 0); no exception or abort crosses the ABI (every entry point's body
+ *     runs inside a catch-all: std::bad_alloc -> MP_ERR_NOMEM, anything else -> MP_ERR_INVALID); the message of the last
+ *     failure on the calling thread is mp_last_error();
  *   - "d_" pointers are device (HBM) pointers on the context's GPU, everything else is host memory;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
  *   - one context drives ONE GPU.  Multi-GPU is one process (and one context) per GPU, tiles sharded across
@@ -17,8 +18,9 @@
  *
  * Seeded mode.  The reference seeds every worker's RNG from the OS (worker.rs:25), so it has no reproducible
  * sample stream.  This library defines one: sample s of pixel (x,y) uses
- *   Xoshiro256++::seed_from_u64(seed + ((y*W + x)*spp + s))
- * followed by the draw order of CameraSampler::sample_ray (camera.rs:176-191).
+ *   Xoshiro256++::seed_from_u64(mix(seed) + ((y*W + x)*spp + s)),   mix(seed) = first SplitMix64 output for state `seed`
+ * followed by the draw order of CameraSampler::sample_ray (camera.rs:176-191).  The seed is mixed before the sample index is
+ * added, so frames rendered with consecutive seeds share no sample streams.
  */
 #ifndef MINIPATH_HIP_H
 #define MINIPATH_HIP_H
@@ -37,6 +39,7 @@ extern "C" {
 #define MP_ERR_HIP 4          /* HIP runtime error */
 #define MP_ERR_UNSUPPORTED 5
 #define MP_ERR_ABORTED 6
+#define MP_ERR_NOMEM 7        /* host allocation failed (std::bad_alloc caught at the boundary) */
 
 #define MP_NO_PRIM 0xFFFFFFFFu /* TriangleIdx::default() (usize::MAX) narrowed to u32, triangle_bvh/mod.rs:143-147 */
 #define MP_LINK_NULL 0xFFFFFFF8u /* CompressedNodeLink::NULL, triangle_bvh/mod.rs:63 */
@@ -98,11 +101,19 @@ typedef struct {
  * pass_begin is the checkpoint (minipath_amd.io.save_checkpoint). */
 #define MP_FLAG_ACCUMULATE 8u
 /* With MP_FLAG_PATHS: staged ("wavefront") evaluation.  The paths of a batch of tiles live in HBM as SoA streams (RNG state, ray,
- * throughput, hit); between two segments the live paths are counting-sorted by (tile, direction bin) so that every wavefront
- * walks 64 rays that start close together and leave in similar directions as ONE packet, instead of eight lanes per incoherent
- * ray.  Same frame, bit for bit, as without the flag (each ray's result is independent of its packet; the per-pixel sum is taken
- * in sample order at the end).  tile_order / d_tile_cost of mp_launch_extras are ignored in this mode. */
+ * throughput, hit); between two segments the live paths are counting-sorted by (tile, direction bin) -- stream compaction plus
+ * cache locality -- and traced 64 per wavefront by the same eight-lanes-per-ray traversal the fused kernel uses (walking the 64
+ * sorted rays as ONE packet was measured 5x slower: DESIGN.md 4.4).  Same frame, bit for bit, as without the flag (each ray's
+ * result is independent of its neighbours; the per-pixel sum is taken in sample order at the end).  tile_order / d_tile_cost of
+ * mp_launch_extras are ignored in this mode. */
 #define MP_FLAG_WAVEFRONT 16u
+/* BUILD-DEFINED accumulation rule for very long sample chains (BASELINE configs[4]: 65 536 spp progressive).  The reference adds
+ * every sample of a pixel into one f32 (worker.rs:40-43); that chain's rounding error grows with its length.  With this flag the
+ * samples are summed in f32, in index order, over chunks of 256 consecutive samples (chunk c = samples [256c, 256c+256)), every
+ * chunk sum is added to an f64 total, and the pixel is (f32)(total * (1.0 / (f64)sample_count)).  Any split of the samples over
+ * MP_FLAG_ACCUMULATE passes gives the same bits (the tile buffer then carries {f32 chunk sum, f64 total (2 floats), hit count}
+ * per pixel between launches).  Defined the same way in oracle/minipath_oracle.c (mpo_set_chunked_sum). */
+#define MP_FLAG_CHUNKED_SUM 32u
 
 /* machinery.rs:180-189 RenderProgressSnapshot */
 typedef struct { size_t finished, total; } mp_progress;
@@ -118,7 +129,33 @@ typedef struct {
     uint32_t stack_bound;    /* exact upper bound of the traversal stack for any ray (<= 7*depth+1) */
     float bbox_min[3], bbox_max[3];
     uint64_t device_bytes;
+    uint32_t material_count; /* max TriangleShadingData.material + 1 (1 for everything the reference builds, building.rs:201) */
+    uint32_t reserved;
 } mp_scene_info;
+
+/* triangle_bvh/mod.rs:20-53 TriangleBvh as arrays in the reference's own layout -- what mp_scene_export emits and
+ * mp_scene_from_arrays takes:
+ *   inner_nodes : inner_count x 128 B  InnerNode       = RelativeBox8 {min.x,min.y,min.z,max.x,max.y,max.z : u16[8]} + u32 links[8]
+ *   packets     : packet_count x 144 B RelativeTriangle8 = 3 vertices x 3 coords x u16[8]
+ *   tri_shading : packet_count*8 x 16 B {u32 vertex_indices[3]; u32 flat_shading}         (TriangleShadingData, usize -> u32)
+ *   tri_material: packet_count*8 x u32  TriangleShadingData.material, may be NULL (= 0, building.rs:201)
+ *   vertex_normals / vertex_tex : vertex_count x 3 f32 (VertexShadingData); vertex_tex may be NULL (origin)
+ *   root_link, bbox : TriangleBvh.root / .bounding_box */
+typedef struct {
+    const void *inner_nodes;
+    const void *packets;
+    const void *tri_shading;
+    const uint32_t *tri_material;
+    const float *vertex_normals;
+    const float *vertex_tex;
+    uint32_t inner_count, packet_count, vertex_count;
+    uint32_t root_link;
+    float bbox_min[3], bbox_max[3];
+} mp_bvh_desc;
+
+/* BUILD-DEFINED path extension (MP_FLAG_PATHS): grey diffuse material, indexed by TriangleShadingData.material.  The
+ * reference carries `material: usize` in every HitRecord (geometry/mod.rs:78) but only ever writes 0 and never reads it. */
+typedef struct { float albedo, emission; } mp_material;
 
 /* geometry/mod.rs:71-80 HitRecord, batched SoA on the device (any pointer may be NULL to skip that output) */
 typedef struct {
@@ -128,6 +165,7 @@ typedef struct {
     float *d_point;         /* n*3, HitRecord.point   (optional) */
     float *d_normal;        /* n*3, HitRecord.normal  (optional) */
     float *d_tex;           /* n*3, HitRecord.texture_coords (optional) */
+    uint32_t *d_material;   /* HitRecord.material (geometry/mod.rs:78), 0 on miss (optional) */
 } mp_hits_soa;
 
 typedef void (*mp_tile_started_cb)(void *user, mp_block tile);                       /* F1, machinery.rs:22 */
@@ -166,6 +204,20 @@ int mp_scene_from_obj(mp_ctx *ctx, const char *path, mp_scene **out);
  * normals/tex may be NULL (=> zero normals => flat shading, building.rs:200). */
 int mp_scene_from_triangles(mp_ctx *ctx, const float *positions, const float *normals, const float *tex,
                             uint32_t vertex_count, const uint32_t *indices, uint32_t triangle_count, mp_scene **out);
+/* Same, with a material id per triangle (NULL = all 0, which is what the reference writes, building.rs:201). */
+int mp_scene_from_triangles_mat(mp_ctx *ctx, const float *positions, const float *normals, const float *tex,
+                                uint32_t vertex_count, const uint32_t *indices, const uint32_t *tri_material,
+                                uint32_t triangle_count, mp_scene **out);
+/* A TriangleBvh the caller already holds (e.g. the Rust reference's own tree, fields of triangle_bvh/mod.rs:20-30): arrays are
+ * copied, links and indices validated (inner nodes must be in pre-order: children after their parent, as building.rs emits
+ * them), nothing is rebuilt -- triangle_index values and the lane order inside leaves are the caller's.  Inverse of
+ * mp_scene_export.  ctx may be NULL (host-only). */
+int mp_scene_from_arrays(mp_ctx *ctx, const mp_bvh_desc *desc, mp_scene **out);
+/* Material table (n >= material_count entries, copied) and sky radiance of the build-defined path extension.  Defaults: one
+ * material {0.75, 0}, sky 1.  Not used by the reference semantics (depth 1). */
+int mp_scene_set_materials(mp_scene *scene, const mp_material *table, uint32_t n, float sky_radiance);
+/* `usemtl` name of material id (OBJ scenes; "" for id 0 = faces before any usemtl); NULL if id >= material_count. */
+const char *mp_scene_material_name(const mp_scene *scene, uint32_t id);
 /* scene/primitives.rs:10-56 Sphere as the scene's Object (analytic intersection, no BVH).  ctx may be NULL (host-only). */
 int mp_scene_sphere(mp_ctx *ctx, const float center[3], float radius, mp_scene **out);
 void mp_scene_destroy(mp_scene *scene);
@@ -175,7 +227,7 @@ int mp_scene_info_get(const mp_scene *scene, mp_scene_info *out);
  * coords x u16[8]), tri shading 16 B (3 x u32 vertex index + u32 flat), vertex normals / tex (n*3 f32).
  * Any pointer may be NULL. */
 int mp_scene_export(const mp_scene *scene, void *inner_nodes, void *packets, void *tri_shading, float *vertex_normals,
-                    float *vertex_tex);
+                    float *vertex_tex, uint32_t *tri_material);
 
 /* ---- impl Object for TriangleBvh :: intersect, batched (ray_bvh_intersection.rs:26-96) -------------------- */
 /* d_o/d_d: SoA device arrays of n floats each (ox,oy,oz / dx,dy,dz).  Directions need not be unit: Ray::new

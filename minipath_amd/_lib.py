@@ -19,6 +19,7 @@ MP_FLAG_TRAVERSAL_GROUPS = 2
 MP_FLAG_PATHS = 4
 MP_FLAG_ACCUMULATE = 8
 MP_FLAG_WAVEFRONT = 16
+MP_FLAG_CHUNKED_SUM = 32
 
 
 class MinipathError(RuntimeError):
@@ -93,7 +94,32 @@ class SceneInfo(C.Structure):
         ("bbox_min", C.c_float * 3),
         ("bbox_max", C.c_float * 3),
         ("device_bytes", C.c_uint64),
+        ("material_count", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
+
+
+class BvhDesc(C.Structure):
+    """mp_bvh_desc: a TriangleBvh as arrays in the reference's own layout (triangle_bvh/mod.rs:20-53)."""
+
+    _fields_ = [
+        ("inner_nodes", C.c_void_p),
+        ("packets", C.c_void_p),
+        ("tri_shading", C.c_void_p),
+        ("tri_material", C.c_void_p),
+        ("vertex_normals", C.c_void_p),
+        ("vertex_tex", C.c_void_p),
+        ("inner_count", C.c_uint32),
+        ("packet_count", C.c_uint32),
+        ("vertex_count", C.c_uint32),
+        ("root_link", C.c_uint32),
+        ("bbox_min", C.c_float * 3),
+        ("bbox_max", C.c_float * 3),
+    ]
+
+
+class Material(C.Structure):
+    _fields_ = [("albedo", C.c_float), ("emission", C.c_float)]
 
 
 class HitsSoA(C.Structure):
@@ -105,6 +131,7 @@ class HitsSoA(C.Structure):
         ("d_point", C.c_void_p),
         ("d_normal", C.c_void_p),
         ("d_tex", C.c_void_p),
+        ("d_material", C.c_void_p),
     ]
 
 
@@ -136,10 +163,17 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)],
     ),
+    "mp_scene_from_triangles_mat": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)],
+    ),
+    "mp_scene_from_arrays": (C.c_int, [C.c_void_p, C.POINTER(BvhDesc), C.POINTER(C.c_void_p)]),
+    "mp_scene_set_materials": (C.c_int, [C.c_void_p, C.POINTER(Material), C.c_uint32, C.c_float]),
+    "mp_scene_material_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "mp_scene_sphere": (C.c_int, [C.c_void_p, _f3, C.c_float, C.POINTER(C.c_void_p)]),
     "mp_scene_destroy": (None, [C.c_void_p]),
     "mp_scene_info_get": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
-    "mp_scene_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mp_scene_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mp_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_void_p] * 6 + [C.c_uint64, C.POINTER(HitsSoA), C.c_void_p]),
     "mp_generate_rays": (
         C.c_int,

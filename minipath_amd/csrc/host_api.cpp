@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <mutex>
 #include <thread>
 
@@ -24,6 +25,23 @@ int fail(int code, const std::string& msg) {
     return code;
 }
 int hip_fail(hipError_t e, const char* what) { return fail(MP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); }
+
+// No exception crosses the C ABI: every extern "C" body runs inside guarded().
+template <class F>
+int guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        try { g_last_error = "out of host memory (std::bad_alloc)"; } catch (...) {}
+        return MP_ERR_NOMEM;
+    } catch (const std::exception& ex) {
+        try { g_last_error = std::string("unexpected exception: ") + ex.what(); } catch (...) {}
+        return MP_ERR_INVALID;
+    } catch (...) {
+        try { g_last_error = "unexpected exception"; } catch (...) {}
+        return MP_ERR_INVALID;
+    }
+}
 
 #define MP_HIP(call)                                  \
     do {                                              \
@@ -106,6 +124,10 @@ struct mp_scene {
     void* d_nodes_aos = nullptr;
     void* d_tris_aos = nullptr;
     void* d_pkt_valid = nullptr;
+    void* d_materials = nullptr;
+    std::vector<mp_material> materials{mp_material{0.75f, 0.0f}};  // build-defined path extension defaults
+    float sky = 1.0f;
+    uint32_t material_count = 1;  // max TriangleShadingData.material + 1
     uint64_t device_bytes = 0;
 };
 
@@ -255,8 +277,9 @@ int upload_scene(mp_scene* s) {
                 for (int k = 0; k < 3; k++) so[a * 3 + k] = h.vnormal[3 * static_cast<size_t>(sh.vi[a]) + k];
                 vidx[(p * 8 + i) * 3 + a] = sh.vi[a];
             }
-            uint32_t flat = sh.flat;
+            uint32_t flat = sh.flat, mat = h.material.empty() ? 0u : h.material[p * 8 + i];
             std::memcpy(&so[9], &flat, 4);
+            std::memcpy(&so[10], &mat, 4);
         }
     }
     // the sign-specialised slab test of the packet walk relies on min <= max for every real child box
@@ -307,6 +330,10 @@ int upload_scene(mp_scene* s) {
     if ((rc = up(&s->d_nodes_aos, nodes_aos.data(), nodes_aos.size() * 4))) return rc;
     if ((rc = up(&s->d_tris_aos, tris_aos.data(), tris_aos.size() * 4))) return rc;
     if ((rc = up(&s->d_pkt_valid, pkt_valid.data(), pkt_valid.size() * 4))) return rc;
+    if ((rc = up(&s->d_materials, s->materials.data(), s->materials.size() * sizeof(mp_material)))) return rc;
+    MP_HIP(hipMemcpy(s->d_materials, s->materials.data(), s->materials.size() * sizeof(mp_material), hipMemcpyHostToDevice));
+    s->dev.materials = static_cast<const float*>(s->d_materials);
+    s->dev.sky = s->sky;
     MP_HIP(hipMemcpy(s->d_nodes_aos, nodes_aos.data(), nodes_aos.size() * 4, hipMemcpyHostToDevice));
     if (!tris_aos.empty()) MP_HIP(hipMemcpy(s->d_tris_aos, tris_aos.data(), tris_aos.size() * 4, hipMemcpyHostToDevice));
     if (!pkt_valid.empty()) MP_HIP(hipMemcpy(s->d_pkt_valid, pkt_valid.data(), pkt_valid.size() * 4, hipMemcpyHostToDevice));
@@ -361,6 +388,10 @@ int upload_scene(mp_scene* s) {
 
 int finish_scene(mp_ctx* ctx, std::unique_ptr<mp_scene> s, mp_scene** out) {
     s->ctx = ctx;
+    uint32_t mc = 0;
+    for (uint32_t m : s->host.material) mc = std::max(mc, m);
+    s->material_count = mc + 1;
+    s->materials.assign(s->material_count, mp_material{0.75f, 0.0f});
     if (!ctx) {  // host-only scene: build + export work, nothing is uploaded and nothing can be rendered
         *out = s.release();
         return MP_OK;
@@ -418,6 +449,7 @@ int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_samp
     L.pass_end = L.pass_begin + pass_samples(st);
     L.carry_in = L.pass_begin > 0;
     L.finalize = L.pass_end == st.sample_count;
+    L.chunked = (st.flags & MP_FLAG_CHUNKED_SUM) != 0;
     std::string err;
     int rc = (st.flags & MP_FLAG_WAVEFRONT) ? launch_render_paths_wavefront(L, stream, err) : launch_render_tiles(L, stream, err);
     if (rc) return fail(rc, err);
@@ -429,9 +461,14 @@ int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_samp
 extern "C" {
 
 const char* mp_last_error(void) { return g_last_error.c_str(); }
-const char* mp_version(void) { return "minipath_hip 0.1 (gfx950)"; }
+const char* mp_version(void) { return "minipath_hip 0.2 (gfx950)"; }
+const char* mp_scene_material_name(const mp_scene* scene, uint32_t id) {
+    if (!scene || id >= scene->material_count) return nullptr;
+    return id < scene->host.material_names.size() ? scene->host.material_names[id].c_str() : "";
+}
 
 int mp_ctx_create(int device_id, mp_ctx** out) {
+    return guarded([&]() -> int {
     if (!out) return fail(MP_ERR_INVALID, "out is NULL");
     int count = 0;
     MP_HIP(hipGetDeviceCount(&count));
@@ -448,6 +485,7 @@ int mp_ctx_create(int device_id, mp_ctx** out) {
     MP_HIP(hipMemset(ctx->d_counters, 0, counter_bytes));
     *out = ctx.release();
     return MP_OK;
+    });
 }
 
 void mp_ctx_destroy(mp_ctx* ctx) {
@@ -460,6 +498,7 @@ void mp_ctx_destroy(mp_ctx* ctx) {
 }
 
 int mp_ctx_set_option(mp_ctx* ctx, const char* key, int value) {
+    return guarded([&]() -> int {
     if (!ctx || !key) return fail(MP_ERR_INVALID, "NULL argument");
     if (std::strcmp(key, "packet_stack_registers") == 0) {
         if (value < 1 || value > 64) return fail(MP_ERR_INVALID, "packet_stack_registers must be in 1..64");
@@ -473,83 +512,146 @@ int mp_ctx_set_option(mp_ctx* ctx, const char* key, int value) {
         return MP_OK;
     }
     return fail(MP_ERR_INVALID, std::string("unknown option: ") + key);
+    });
 }
 
 int mp_ctx_device(const mp_ctx* ctx, int* device_id, int* cu_count) {
+    return guarded([&]() -> int {
     if (!ctx) return fail(MP_ERR_INVALID, "ctx is NULL");
     if (device_id) *device_id = ctx->device;
     if (cu_count) *cu_count = ctx->cu_count;
     return MP_OK;
+    });
 }
 
 // ---- camera ---------------------------------------------------------------------------------------------------
 int mp_camera_default(mp_camera* cam) {
+    return guarded([&]() -> int {
     if (!cam) return fail(MP_ERR_INVALID, "cam is NULL");
     camera_default(*cam);
     return MP_OK;
+    });
 }
 int mp_camera_look_at(mp_camera* cam, const float eye[3], const float at[3], const float up[3]) {
+    return guarded([&]() -> int {
     if (!cam || !eye || !at || !up) return fail(MP_ERR_INVALID, "NULL argument");
     camera_look_at(*cam, eye, at, up);
     return MP_OK;
+    });
 }
 int mp_camera_look_direction(mp_camera* cam, const float eye[3], const float fwd[3], const float up[3]) {
+    return guarded([&]() -> int {
     if (!cam || !eye || !fwd || !up) return fail(MP_ERR_INVALID, "NULL argument");
     camera_look_direction(*cam, eye, fwd, up);
     return MP_OK;
+    });
 }
 int mp_camera_translate(mp_camera* cam, const float t[3]) {
+    return guarded([&]() -> int {
     if (!cam || !t) return fail(MP_ERR_INVALID, "NULL argument");
     for (int k = 0; k < 3; k++) cam->t[k] = t[k] + cam->t[k];  // (Translation3 * Isometry3).translation
     return MP_OK;
+    });
 }
 int mp_camera_basis(const mp_camera* cam, float center[3], float fwd[3], float up[3], float right[3]) {
+    return guarded([&]() -> int {
     if (!cam || !center || !fwd || !up || !right) return fail(MP_ERR_INVALID, "NULL argument");
     camera_basis(*cam, center, fwd, up, right);
     return MP_OK;
+    });
 }
 int mp_camera_build_sampler(const mp_camera* cam, uint32_t width, uint32_t height, mp_camera_sampler* out) {
+    return guarded([&]() -> int {
     if (!cam || !out) return fail(MP_ERR_INVALID, "NULL argument");
     if (width == 0 || height == 0) return fail(MP_ERR_INVALID, "empty resolution");
     camera_build_sampler(*cam, width, height, *out);
     return MP_OK;
+    });
 }
 
 int mp_tile_ordering(mp_block block, uint32_t tile_size, uint64_t shuffle_seed, mp_block* out, size_t cap, size_t* n) {
+    return guarded([&]() -> int {
     if (tile_size == 0) return fail(MP_ERR_INVALID, "tile_size must be non-zero (NonZeroU32)");
     if (!n) return fail(MP_ERR_INVALID, "n is NULL");
     std::vector<mp_block> t = tile_ordering(block, tile_size, shuffle_seed);
     *n = t.size();
     if (out) std::memcpy(out, t.data(), std::min(cap, t.size()) * sizeof(mp_block));
     return MP_OK;
+    });
 }
 
 // ---- scene ----------------------------------------------------------------------------------------------------
 int mp_scene_from_obj(mp_ctx* ctx, const char* path, mp_scene** out) {
+    return guarded([&]() -> int {
     if (!path || !out) return fail(MP_ERR_INVALID, "NULL argument");
     std::vector<float> pos, nrm, tex;
-    std::vector<uint32_t> tri;
+    std::vector<uint32_t> tri, tri_mat;
+    std::vector<std::string> names;
     std::string err;
-    int rc = load_obj(path, pos, nrm, tex, tri, err);
+    int rc = load_obj(path, pos, nrm, tex, tri, tri_mat, names, err);
     if (rc) return fail(rc, err);
     auto s = std::make_unique<mp_scene>();
-    rc = build_bvh(pos.data(), nrm.data(), tex.data(), static_cast<uint32_t>(pos.size() / 3), tri.data(),
+    rc = build_bvh(pos.data(), nrm.data(), tex.data(), static_cast<uint32_t>(pos.size() / 3), tri.data(), tri_mat.data(),
                    static_cast<uint32_t>(tri.size() / 3), s->host, err);
     if (rc) return fail(rc, err);
+    s->host.material_names = std::move(names);
     return finish_scene(ctx, std::move(s), out);
+    });
 }
 
 int mp_scene_from_triangles(mp_ctx* ctx, const float* positions, const float* normals, const float* tex,
                             uint32_t vertex_count, const uint32_t* indices, uint32_t triangle_count, mp_scene** out) {
+    return mp_scene_from_triangles_mat(ctx, positions, normals, tex, vertex_count, indices, nullptr, triangle_count, out);
+}
+
+int mp_scene_from_triangles_mat(mp_ctx* ctx, const float* positions, const float* normals, const float* tex,
+                                uint32_t vertex_count, const uint32_t* indices, const uint32_t* tri_material,
+                                uint32_t triangle_count, mp_scene** out) {
+    return guarded([&]() -> int {
     if (!positions || !indices || !out) return fail(MP_ERR_INVALID, "NULL argument");
     auto s = std::make_unique<mp_scene>();
     std::string err;
-    int rc = build_bvh(positions, normals, tex, vertex_count, indices, triangle_count, s->host, err);
+    int rc = build_bvh(positions, normals, tex, vertex_count, indices, tri_material, triangle_count, s->host, err);
     if (rc) return fail(rc, err);
     return finish_scene(ctx, std::move(s), out);
+    });
+}
+
+int mp_scene_from_arrays(mp_ctx* ctx, const mp_bvh_desc* desc, mp_scene** out) {
+    return guarded([&]() -> int {
+    if (!desc || !out) return fail(MP_ERR_INVALID, "NULL argument");
+    auto s = std::make_unique<mp_scene>();
+    std::string err;
+    int rc = bvh_from_arrays(*desc, s->host, err);
+    if (rc) return fail(rc, err);
+    return finish_scene(ctx, std::move(s), out);
+    });
+}
+
+int mp_scene_set_materials(mp_scene* scene, const mp_material* table, uint32_t n, float sky_radiance) {
+    return guarded([&]() -> int {
+    if (!scene || !table) return fail(MP_ERR_INVALID, "NULL argument");
+    if (scene->dev.kind != 0u) return fail(MP_ERR_UNSUPPORTED, "materials belong to TriangleBvh scenes");
+    if (n < scene->material_count) return fail(MP_ERR_INVALID, "material table shorter than the scene's material_count");
+    scene->materials.assign(table, table + n);
+    scene->sky = sky_radiance;
+    if (scene->ctx) {  // re-upload the table; renders already enqueued keep the old one alive until the device is idle
+        DeviceGuard g(scene->ctx->device);
+        void* d_new = nullptr;
+        MP_HIP(hipMalloc(&d_new, std::max<size_t>(16, n * sizeof(mp_material))));
+        hipError_t e = hipMemcpy(d_new, scene->materials.data(), n * sizeof(mp_material), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d_new); return hip_fail(e, "hipMemcpy(materials)"); }
+        if (scene->d_materials) (void)hipFree(scene->d_materials);  // hipFree waits for the device
+        scene->d_materials = d_new;
+        scene->dev.materials = static_cast<const float*>(d_new);
+        scene->dev.sky = sky_radiance;
+    }
+    return MP_OK;
+    });
 }
 
 int mp_scene_sphere(mp_ctx* ctx, const float center[3], float radius, mp_scene** out) {
+    return guarded([&]() -> int {
     if (!center || !out) return fail(MP_ERR_INVALID, "NULL argument");
     auto s = std::make_unique<mp_scene>();
     s->ctx = ctx;
@@ -563,19 +665,21 @@ int mp_scene_sphere(mp_ctx* ctx, const float center[3], float radius, mp_scene**
     s->dev.stack_cap = 1;
     *out = s.release();
     return MP_OK;
+    });
 }
 
 void mp_scene_destroy(mp_scene* s) {
     if (!s) return;
     if (s->ctx) {
         DeviceGuard g(s->ctx->device);
-        for (void* p : {s->d_shade, s->d_vidx, s->d_vtex, s->d_nodes_aos, s->d_tris_aos, s->d_pkt_valid})
+        for (void* p : {s->d_shade, s->d_vidx, s->d_vtex, s->d_nodes_aos, s->d_tris_aos, s->d_pkt_valid, s->d_materials})
             if (p) (void)hipFree(p);
     }
     delete s;
 }
 
 int mp_scene_info_get(const mp_scene* s, mp_scene_info* out) {
+    return guarded([&]() -> int {
     if (!s || !out) return fail(MP_ERR_INVALID, "NULL argument");
     out->root_link = s->host.root;
     out->inner_count = static_cast<uint32_t>(s->host.inner.size());
@@ -589,11 +693,15 @@ int mp_scene_info_get(const mp_scene* s, mp_scene_info* out) {
         out->bbox_max[k] = s->host.bbox.mx[k];
     }
     out->device_bytes = s->device_bytes;
+    out->material_count = s->material_count;
+    out->reserved = 0;
     return MP_OK;
+    });
 }
 
 int mp_scene_export(const mp_scene* s, void* inner_nodes, void* packets, void* tri_shading, float* vertex_normals,
-                    float* vertex_tex) {
+                    float* vertex_tex, uint32_t* tri_material) {
+    return guarded([&]() -> int {
     if (!s) return fail(MP_ERR_INVALID, "scene is NULL");
     const HostBvh& h = s->host;
     if (inner_nodes && !h.inner.empty()) std::memcpy(inner_nodes, h.inner.data(), h.inner.size() * sizeof(InnerNodeRef));
@@ -601,13 +709,16 @@ int mp_scene_export(const mp_scene* s, void* inner_nodes, void* packets, void* t
     if (tri_shading && !h.shading.empty()) std::memcpy(tri_shading, h.shading.data(), h.shading.size() * sizeof(TriShadingRef));
     if (vertex_normals && !h.vnormal.empty()) std::memcpy(vertex_normals, h.vnormal.data(), h.vnormal.size() * 4);
     if (vertex_tex && !h.vtex.empty()) std::memcpy(vertex_tex, h.vtex.data(), h.vtex.size() * 4);
+    if (tri_material && !h.material.empty()) std::memcpy(tri_material, h.material.data(), h.material.size() * 4);
     return MP_OK;
+    });
 }
 
 // ---- rays -------------------------------------------------------------------------------------------------------
 int mp_trace_rays(mp_ctx* ctx, const mp_scene* scene, const float* d_ox, const float* d_oy, const float* d_oz,
                   const float* d_dx, const float* d_dy, const float* d_dz, uint64_t n, const mp_hits_soa* hits,
                   void* stream) {
+    return guarded([&]() -> int {
     if (!ctx || !scene || !hits) return fail(MP_ERR_INVALID, "NULL argument");
     if (n && (!d_ox || !d_oy || !d_oz || !d_dx || !d_dy || !d_dz)) return fail(MP_ERR_INVALID, "NULL ray array");
     if (scene->ctx != ctx) return fail(MP_ERR_INVALID, "scene belongs to another context");
@@ -616,11 +727,13 @@ int mp_trace_rays(mp_ctx* ctx, const mp_scene* scene, const float* d_ox, const f
     int rc = launch_trace_rays(scene->dev, d_ox, d_oy, d_oz, d_dx, d_dy, d_dz, n, *hits, ctx->cu_count, stream, err);
     if (rc) return fail(rc, err);
     return MP_OK;
+    });
 }
 
 int mp_generate_rays(mp_ctx* ctx, const mp_camera_sampler* sampler, const mp_settings* settings, mp_block block,
                      uint32_t sample, float* d_ox, float* d_oy, float* d_oz, float* d_dx, float* d_dy, float* d_dz,
                      void* stream) {
+    return guarded([&]() -> int {
     if (!ctx || !sampler || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
     if (!(block.min_x <= block.max_x && block.min_y <= block.max_y)) return fail(MP_ERR_INVALID, "inverted block");
     if (!d_ox || !d_oy || !d_oz || !d_dx || !d_dy || !d_dz) return fail(MP_ERR_INVALID, "NULL ray array");
@@ -630,25 +743,31 @@ int mp_generate_rays(mp_ctx* ctx, const mp_camera_sampler* sampler, const mp_set
                                   d_oy, d_oz, d_dx, d_dy, d_dz, stream, err);
     if (rc) return fail(rc, err);
     return MP_OK;
+    });
 }
 
 // ---- tiles ------------------------------------------------------------------------------------------------------
 int mp_render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler,
                            const mp_settings* settings, const mp_block* tiles, size_t n_tiles, float* d_rgba_f32,
                            void* stream) {
+    return guarded([&]() -> int {
     return mp_render_tiles_device_counted(ctx, scene, sampler, settings, tiles, n_tiles, d_rgba_f32, nullptr, stream);
+    });
 }
 
 int mp_render_tiles_device_counted(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler,
                                    const mp_settings* settings, const mp_block* tiles, size_t n_tiles, float* d_rgba_f32,
                                    uint64_t* d_ray_segments, void* stream) {
+    return guarded([&]() -> int {
     mp_launch_extras ex{d_ray_segments, nullptr, nullptr};
     return mp_render_tiles_device_ex(ctx, scene, sampler, settings, tiles, n_tiles, d_rgba_f32, &ex, stream);
+    });
 }
 
 int mp_render_tiles_device_ex(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler, const mp_settings* settings,
                               const mp_block* tiles, size_t n_tiles, float* d_rgba_f32, const mp_launch_extras* extras,
                               void* stream) {
+    return guarded([&]() -> int {
     if (!ctx || !scene || !sampler || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
     if (n_tiles && (!tiles || !d_rgba_f32)) return fail(MP_ERR_INVALID, "NULL tiles/output");
     if (scene->ctx != ctx) return fail(MP_ERR_INVALID, "scene belongs to another context");
@@ -686,10 +805,12 @@ int mp_render_tiles_device_ex(mp_ctx* ctx, const mp_scene* scene, const mp_camer
     }
     if (!rc) rc = render_tiles_device(ctx, scene, *sampler, *settings, d_tiles, n_tiles, d_rgba_f32, stream, d_ray_segments, d_order, d_tile_cost);
     return rc;
+    });
 }
 
 int mp_untile(mp_ctx* ctx, const mp_settings* settings, const mp_block* tiles, size_t n_tiles, const float* d_tiles_f32,
               float* d_image_f32, uint8_t* d_image_u8, void* stream) {
+    return guarded([&]() -> int {
     if (!ctx || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
     if (n_tiles == 0) return MP_OK;
     if (!tiles || !d_tiles_f32) return fail(MP_ERR_INVALID, "NULL tiles/input");
@@ -703,10 +824,12 @@ int mp_untile(mp_ctx* ctx, const mp_settings* settings, const mp_block* tiles, s
                        d_image_f32, d_image_u8, stream, err);
     if (rc) fail(rc, err);
     return rc;
+    });
 }
 
 int mp_render_tile(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler, const mp_settings* settings,
                    mp_block tile, float* rgba_f32, uint8_t* rgba_u8) {
+    return guarded([&]() -> int {
     if (!ctx || !scene || !sampler || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
     if (settings->flags & MP_FLAG_ACCUMULATE) return fail(MP_ERR_INVALID, "MP_FLAG_ACCUMULATE needs a caller-owned device tile buffer: use mp_render_tiles_device");
     if (!(tile.min_x < tile.max_x && tile.min_y < tile.max_y)) return MP_OK;  // empty tile: internal_points yields nothing
@@ -732,6 +855,7 @@ int mp_render_tile(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* 
                 for (int k = 0; k < 4; k++) rgba_u8[(static_cast<size_t>(y) * w + x) * 4 + k] = to_u8(p[k]);
         }
     return MP_OK;
+    });
 }
 
 }  // extern "C"
@@ -861,6 +985,7 @@ extern "C" {
 
 int mp_render_begin(mp_ctx* ctx, const mp_scene* scene, const mp_camera* camera, const mp_settings* settings,
                     mp_tile_started_cb started, mp_tile_finished_cb finished, void* user, mp_render** out) {
+    return guarded([&]() -> int {
     if (!ctx || !scene || !camera || !out || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
     if (settings->flags & MP_FLAG_ACCUMULATE) return fail(MP_ERR_INVALID, "render() draws every sample of a tile at once (worker.rs:32-49): MP_FLAG_ACCUMULATE is for mp_render_tiles_device");
     if (scene->ctx != ctx) return fail(MP_ERR_INVALID, "scene belongs to another context");
@@ -886,22 +1011,28 @@ int mp_render_begin(mp_ctx* ctx, const mp_scene* scene, const mp_camera* camera,
     }
     *out = r.release();
     return MP_OK;
+    });
 }
 
 int mp_render_progress(const mp_render* r, mp_progress* out) {
+    return guarded([&]() -> int {
     if (!r || !out) return fail(MP_ERR_INVALID, "NULL argument");
     out->finished = r->done_tiles.load(std::memory_order_acquire);
     out->total = r->tiles.size();
     return MP_OK;
+    });
 }
 
 int mp_render_is_finished(const mp_render* r, int* finished) {
+    return guarded([&]() -> int {
     if (!r || !finished) return fail(MP_ERR_INVALID, "NULL argument");
     *finished = r->finished_flag.load(std::memory_order_acquire) ? 1 : 0;
     return MP_OK;
+    });
 }
 
 int mp_render_elapsed_ns(const mp_render* rc, uint64_t* ns) {
+    return guarded([&]() -> int {
     if (!rc || !ns) return fail(MP_ERR_INVALID, "NULL argument");
     mp_render* r = const_cast<mp_render*>(rc);
     std::lock_guard<std::mutex> lk(r->end_mu);
@@ -909,33 +1040,42 @@ int mp_render_elapsed_ns(const mp_render* rc, uint64_t* ns) {
                       : std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - r->start);
     *ns = static_cast<uint64_t>(d.count());
     return MP_OK;
+    });
 }
 
 int mp_render_abort(mp_render* r) {
+    return guarded([&]() -> int {
     if (!r) return fail(MP_ERR_INVALID, "NULL argument");
     r->next_tile.store(r->tiles.size(), std::memory_order_release);  // machinery.rs:161-165
     return MP_OK;
+    });
 }
 
 int mp_render_wait(mp_render* r) {
+    return guarded([&]() -> int {
     if (!r) return fail(MP_ERR_INVALID, "NULL argument");
     if (r->worker.joinable()) r->worker.join();
     if (r->status != MP_OK) return fail(r->status, r->error);
     return MP_OK;
+    });
 }
 
 int mp_render_image_u8(mp_render* r, uint8_t* dst) {
+    return guarded([&]() -> int {
     if (!r || !dst) return fail(MP_ERR_INVALID, "NULL argument");
     std::lock_guard<std::mutex> lk(r->image_mu);
     std::memcpy(dst, r->image_u8.data(), r->image_u8.size());
     return MP_OK;
+    });
 }
 
 int mp_render_image_f32(mp_render* r, float* dst) {
+    return guarded([&]() -> int {
     if (!r || !dst) return fail(MP_ERR_INVALID, "NULL argument");
     std::lock_guard<std::mutex> lk(r->image_mu);
     std::memcpy(dst, r->image_f32.data(), r->image_f32.size() * 4);
     return MP_OK;
+    });
 }
 
 void mp_render_destroy(mp_render* r) {

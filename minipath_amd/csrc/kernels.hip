@@ -97,7 +97,7 @@ struct RayGen {
     mp_camera_sampler s;
     float jitter_scale;  // UniformFloat::new_inclusive(-0.5, 0.5).scale, computed on the host
     uint32_t width, spp;
-    uint64_t seed;
+    uint64_t seed;  // mix(settings.seed), see mixed_seed()
 };
 
 struct Ray {
@@ -141,6 +141,7 @@ __device__ __forceinline__ void sample_ray_rng(const RayGen& P, uint32_t x, uint
             ly * P.s.lens_weight - fy, lz * P.s.lens_weight - fz, r);
 }
 
+// key = mix(seed) + sample index; `P.seed` already holds mix(seed) (mixed_seed(), on the host)
 __device__ __forceinline__ uint64_t sample_key(const RayGen& P, uint32_t x, uint32_t y, uint32_t sample) {
     return P.seed + ((static_cast<uint64_t>(y) * P.width + x) * P.spp + sample);
 }
@@ -298,7 +299,8 @@ __device__ __forceinline__ bool may_hit_scene(const DevScene& sc, const Ray& r) 
 
 // Hit resolve + shade: tail of intersect (ray_bvh_intersection.rs:66-95) and render_sample (worker.rs:59-65).
 // Returns |dot(ray.direction, normal)|.
-__device__ __forceinline__ void resolve_normal(const DevScene& sc, uint32_t prim, float u, float v, float n[3]) {
+// Returns TriangleShadingData.material of the triangle (mod.rs:44; 0 for everything the reference builds).
+__device__ __forceinline__ uint32_t resolve_normal(const DevScene& sc, uint32_t prim, float u, float v, float n[3]) {
     const float4* sh = reinterpret_cast<const float4*>(sc.shade) + static_cast<size_t>(prim) * 3;
     float4 a = sh[0], b = sh[1], c = sh[2];
     float nx, ny, nz;
@@ -317,6 +319,7 @@ __device__ __forceinline__ void resolve_normal(const DevScene& sc, uint32_t prim
     }
     float len = sqrtf(nx * nx + ny * ny + nz * nz);
     n[0] = nx / len; n[1] = ny / len; n[2] = nz / len;
+    return as_u(c.z);
 }
 
 // impl Object for Sphere::intersect, scene/primitives.rs:16-48 (lane-parallel; n = unit normal at the hit)
@@ -350,6 +353,7 @@ struct RenderParams {
     uint32_t s_begin, s_end;  // samples of this launch (progressive accumulation: a sub-range of [0, spp))
     uint32_t carry_in;    // out holds the running sums / hit counts of samples [0, s_begin)
     uint32_t finalize;    // write the means (worker.rs:44); otherwise the running sums
+    uint32_t chunked;     // MP_FLAG_CHUNKED_SUM: f32 sums over 256-sample chunks, f64 total kept in the tile buffer
     const uint32_t* tile_order;      // optional hand-out order: work slot k renders tile tile_order[k] (into that tile's own slot)
     unsigned long long* tile_cost;   // optional: += shader-clock cycles the waves spent on each tile
     uint32_t lds_per_wave;
@@ -359,16 +363,44 @@ struct RenderParams {
 
 // worker.rs:40-44 with the running state of a pixel carried across launches (MP_FLAG_ACCUMULATE): rgb = sequential sample sum,
 // a = hit count; the launch that draws the last sample writes the means.  Every lane of the pixel loads the same state.
-__device__ __forceinline__ void pixel_state_load(const RenderParams& P, size_t off, bool inpix, float& acc, float& cnt) {
+//
+// MP_FLAG_CHUNKED_SUM (build-defined, include/minipath_hip.h): the pixel's slot holds {x: f32 sum of the current 256-sample
+// chunk, y: hit count, (z,w): f64 total of the finished chunks}.  The total stays in memory (one read-modify-write per pixel and
+// chunk by the pixel's first lane), so the rule costs the render kernels no registers.
+constexpr uint32_t kSumChunk = 256;
+__device__ __forceinline__ void pixel_state_load(const RenderParams& P, size_t off, bool inpix, bool writer, float& acc, float& cnt) {
     acc = 0.0f;
     cnt = 0.0f;
     if (P.carry_in && inpix) {
         const float4 prev = *reinterpret_cast<const float4*>(P.out + off);
         acc = prev.x;
-        cnt = prev.w;
+        cnt = P.chunked ? prev.y : prev.w;
+    } else if (P.chunked && inpix && writer) {
+        *reinterpret_cast<double*>(P.out + off + 2) = 0.0;
     }
 }
+// end of a chunk: total += (f64)chunk sum; the next chunk starts from +0
+__device__ __forceinline__ void chunk_flush(const RenderParams& P, size_t off, bool writer, float& acc) {
+    if (writer) {
+        double* t = reinterpret_cast<double*>(P.out + off + 2);
+        *t = *t + static_cast<double>(acc);
+    }
+    acc = 0.0f;
+}
+// `s_next` = index of the first sample NOT yet added (the launch's s_end)
 __device__ __forceinline__ void pixel_state_store(const RenderParams& P, size_t off, float acc, float cnt) {
+    if (P.chunked) {
+        if (!P.finalize) {
+            *reinterpret_cast<float2*>(P.out + off) = make_float2(acc, cnt);
+            return;
+        }
+        double t = *reinterpret_cast<const double*>(P.out + off + 2);
+        if ((P.s_end & (kSumChunk - 1u)) != 0u) t = t + static_cast<double>(acc);  // the last, partial chunk
+        const double inv = 1.0 / static_cast<double>(P.gen.spp);
+        const float m = static_cast<float>(t * inv), a = static_cast<float>(static_cast<double>(cnt) * inv);
+        *reinterpret_cast<float4*>(P.out + off) = make_float4(m, m, m, a);
+        return;
+    }
     const float m = P.finalize ? acc * P.inv_spp : acc;  // worker.rs:44
     const float a = P.finalize ? cnt * P.inv_spp : cnt;
     *reinterpret_cast<float4*>(P.out + off) = make_float4(m, m, m, a);
@@ -421,10 +453,12 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
         if (__ballot(inpix) == 0) continue;
         const size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
         float acc, cnt;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
-        pixel_state_load(P, off, inpix, acc, cnt);
-        for (uint32_t s0 = P.s_begin; s0 < P.s_end; s0 += S) {
+        pixel_state_load(P, off, inpix, sub == 0, acc, cnt);
+        // passes are aligned to multiples of S in the absolute sample index, so that a chunk boundary (MP_FLAG_CHUNKED_SUM) never
+        // falls inside a pass; lanes outside [s_begin, s_end) add +0.0, which is exact
+        for (uint32_t s0 = P.s_begin & ~static_cast<uint32_t>(S - 1); s0 < P.s_end; s0 += S) {
             const uint32_t s = s0 + static_cast<uint32_t>(sub);
-            const bool act = inpix && s < P.s_end;
+            const bool act = inpix && s >= P.s_begin && s < P.s_end;
             Ray r;
             r.dx = r.dy = r.dz = 0.0f;
             if (act) sample_ray(P.gen, px, py, s, r);
@@ -436,6 +470,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
                     acc += __shfl(c, (lane & ~(S - 1)) + j);
                     cnt += __shfl(h, (lane & ~(S - 1)) + j);
                 }
+                if (P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) chunk_flush(P, off, inpix && sub == 0, acc);
                 continue;
             }
             // compaction of the lanes whose ray can reach the scene into the wave's ray queue
@@ -465,6 +500,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
                 acc += __shfl(c, (lane & ~(S - 1)) + j);
                 cnt += __shfl(h, (lane & ~(S - 1)) + j);
             }
+            if (P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) chunk_flush(P, off, inpix && sub == 0, acc);
         }
         if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
         if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
@@ -806,10 +842,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
         if (__ballot(inpix) == 0) continue;
         const size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
         float acc, cnt;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
-        pixel_state_load(P, off, inpix, acc, cnt);
-        for (uint32_t s0 = P.s_begin; s0 < P.s_end; s0 += S) {
+        pixel_state_load(P, off, inpix, sub == 0, acc, cnt);
+        // passes are aligned to multiples of S in the absolute sample index, so that a chunk boundary (MP_FLAG_CHUNKED_SUM) never
+        // falls inside a pass; lanes outside [s_begin, s_end) add +0.0, which is exact
+        for (uint32_t s0 = P.s_begin & ~static_cast<uint32_t>(S - 1); s0 < P.s_end; s0 += S) {
             const uint32_t s = s0 + static_cast<uint32_t>(sub);
-            const bool act = inpix && s < P.s_end;
+            const bool act = inpix && s >= P.s_begin && s < P.s_end;
             Ray r;
             r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
             if (act) sample_ray(P.gen, px, py, s, r);
@@ -840,6 +878,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
             // alpha sums 1.0 per hit: an exact integer in f32, so the order is irrelevant
             cnt += static_cast<float>(__popcll(__ballot(hit) & pixel_lanes));
             add_samples_in_order<S>(acc, c, lane);  // misses add +0.0 (exact)
+            if (P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) chunk_flush(P, off, inpix && sub == 0, acc);
         }
         if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
         if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
@@ -847,11 +886,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 }
 
 // ---- build-defined path extension (MP_FLAG_PATHS; the reference has no bounce loop) -----------------
-// Diffuse grey surfaces (albedo 0.75) under a uniform white sky, at most max_depth segments per path; the operations and
-// their order are those of the oracle's render_sample_paths_impl (only + - * / sqrt and compares => bit-identical).
+// Diffuse grey surfaces {albedo, emission} indexed by TriangleShadingData.material under a uniform sky (defaults: one material
+// {0.75, 0}, sky 1), at most max_depth segments per path; the operations and their order are those of the oracle's
+// render_sample_paths_impl (only + - * / sqrt and compares => bit-identical).
 // Camera rays are coherent and go through the packet walk; bounce rays are incoherent: the lanes whose path is still
 // alive are compacted (ballot + mbcnt) into the wave's LDS ray queue and traced by the 8-lane-group traversal.
-constexpr float kPathAlbedo = 0.75f;
 constexpr float kPathEps = 1e-4f;
 
 // One path vertex of the build-defined extension (oracle: render_sample_paths_impl), shared by the fused and the staged kernels so
@@ -860,15 +899,17 @@ constexpr float kPathEps = 1e-4f;
 __device__ __forceinline__ bool path_vertex(const DevScene& sc, const PacketHit& h, uint32_t depth, uint32_t max_depth, Rng& rng,
                                             Ray& r, float& L, float& thr, bool& primary_hit) {
     if (h.prim == kNoPrim) {
-        L = thr;  // sky radiance 1
+        L = L + thr * sc.sky;
         return false;
     }
     if (depth == 1) primary_hit = true;
     float n[3];
-    resolve_normal(sc, h.prim, h.u, h.v, n);
+    const uint32_t mat = resolve_normal(sc, h.prim, h.u, h.v, n);
+    const float2 m = reinterpret_cast<const float2*>(sc.materials)[mat];  // {albedo, emission}
+    L = L + thr * m.y;
     const float dn = r.dx * n[0] + r.dy * n[1] + r.dz * n[2];
     if (dn > 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-    thr = thr * kPathAlbedo;
+    thr = thr * m.x;
     if (depth == max_depth) return false;
     const float hx = r.ox + r.dx * h.t, hy = r.oy + r.dy * h.t, hz = r.oz + r.dz * h.t;  // geometry/mod.rs:56-58
     float x1, x2;
@@ -911,10 +952,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         if (__ballot(inpix) == 0) continue;
         const size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
         float acc, cnt;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
-        pixel_state_load(P, off, inpix, acc, cnt);
-        for (uint32_t s0 = P.s_begin; s0 < P.s_end; s0 += S) {
+        pixel_state_load(P, off, inpix, sub == 0, acc, cnt);
+        // passes are aligned to multiples of S in the absolute sample index, so that a chunk boundary (MP_FLAG_CHUNKED_SUM) never
+        // falls inside a pass; lanes outside [s_begin, s_end) add +0.0, which is exact
+        for (uint32_t s0 = P.s_begin & ~static_cast<uint32_t>(S - 1); s0 < P.s_end; s0 += S) {
             const uint32_t s = s0 + static_cast<uint32_t>(sub);
-            const bool act = inpix && s < P.s_end;
+            const bool act = inpix && s >= P.s_begin && s < P.s_end;
             Rng rng;
             rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
             Ray r;
@@ -960,6 +1003,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             }
             cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
             add_samples_in_order<S>(acc, L, lane);
+            if (P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) chunk_flush(P, off, inpix && sub == 0, acc);
         }
         if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
         if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
@@ -1006,7 +1050,7 @@ struct WfParams {
     uint32_t depth, max_depth;
     float* out;
     float inv_spp;
-    uint32_t carry_in, finalize;
+    uint32_t carry_in, finalize, chunked;
     uint32_t lds_per_wave;
     unsigned long long* segments;
     WfState st;
@@ -1212,16 +1256,31 @@ __global__ __launch_bounds__(256) void wf_accumulate_kernel(WfParams P) {
         if (!(T.min_x + x < T.max_x && T.min_y + y < T.max_y)) continue;
         float* o = P.out + (static_cast<size_t>(P.tile_base + tile_l) * ts * ts + q) * 4;
         float acc = 0.0f, cnt = 0.0f;
+        double tot = 0.0;  // MP_FLAG_CHUNKED_SUM: slot = {chunk sum, hit count, f64 total} (pixel_state_load)
         if (P.carry_in) {
             const float4 prev = *reinterpret_cast<const float4*>(o);
             acc = prev.x;
-            cnt = prev.w;
+            cnt = P.chunked ? prev.y : prev.w;
+            if (P.chunked) tot = *reinterpret_cast<const double*>(o + 2);
         }
         const uint32_t ns = min(P.sc, P.s_end - P.s0);
         const uint32_t pbase = i * P.sc;
         for (uint32_t sl = 0; sl < ns; sl++) {
             acc += P.st.L[pbase + sl];
             cnt += (P.st.flags[pbase + sl] & kWfPrimaryHit) ? 1.0f : 0.0f;
+            if (P.chunked && ((P.s0 + sl + 1u) & (kSumChunk - 1u)) == 0u) { tot = tot + static_cast<double>(acc); acc = 0.0f; }
+        }
+        if (P.chunked) {
+            if (!P.finalize) {
+                *reinterpret_cast<float2*>(o) = make_float2(acc, cnt);
+                *reinterpret_cast<double*>(o + 2) = tot;
+                continue;
+            }
+            if (((P.s0 + ns) & (kSumChunk - 1u)) != 0u) tot = tot + static_cast<double>(acc);
+            const double inv = 1.0 / static_cast<double>(P.gen.spp);
+            const float m = static_cast<float>(tot * inv), a = static_cast<float>(static_cast<double>(cnt) * inv);
+            *reinterpret_cast<float4*>(o) = make_float4(m, m, m, a);
+            continue;
         }
         const float m = P.finalize ? acc * P.inv_spp : acc, a = P.finalize ? cnt * P.inv_spp : cnt;
         *reinterpret_cast<float4*>(o) = make_float4(m, m, m, a);
@@ -1266,6 +1325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     if (P.hits.d_normal) P.hits.d_normal[i * 3 + k] = hit ? nn[k] : 0.0f;
                     if (P.hits.d_tex) P.hits.d_tex[i * 3 + k] = 0.0f;
                 }
+                if (P.hits.d_material) P.hits.d_material[i] = 0u;
             }
             continue;
         }
@@ -1286,10 +1346,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if (P.hits.d_prim) P.hits.d_prim[i] = prim;
             if (P.hits.d_u) P.hits.d_u[i] = u;
             if (P.hits.d_v) P.hits.d_v[i] = v;
-            if (P.hits.d_point || P.hits.d_normal || P.hits.d_tex) {
+            if (P.hits.d_point || P.hits.d_normal || P.hits.d_tex || P.hits.d_material) {
                 float pt[3] = {0, 0, 0}, nn[3] = {0, 0, 0}, tx[3] = {0, 0, 0};
+                uint32_t mat = 0;  // HitRecord.material (geometry/mod.rs:78)
                 if (prim != kNoPrim) {
-                    resolve_normal(P.scene, prim, u, v, nn);
+                    mat = resolve_normal(P.scene, prim, u, v, nn);
                     Ray r;  // rebuilt here so that no ray registers stay live across the walk
                     ray_new(P.ox[i], P.oy[i], P.oz[i], P.dx[i], P.dy[i], P.dz[i], r);
                     pt[0] = r.ox + r.dx * t; pt[1] = r.oy + r.dy * t; pt[2] = r.oz + r.dz * t;  // geometry/mod.rs:56-58
@@ -1304,6 +1365,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     if (P.hits.d_normal) P.hits.d_normal[i * 3 + k] = nn[k];
                     if (P.hits.d_tex) P.hits.d_tex[i * 3 + k] = tx[k];
                 }
+                if (P.hits.d_material) P.hits.d_material[i] = mat;
             }
         }
         wave_lds_sync();
@@ -1381,6 +1443,15 @@ float uniform_inclusive_scale(float low, float high) {
     return scale;
 }
 
+// Seeded mode (include/minipath_hip.h): the first SplitMix64 output for state `seed`, so that consecutive seeds give unrelated
+// sample streams; the per-sample index is added on the device (sample_key).
+uint64_t mixed_seed(uint64_t seed) {
+    uint64_t z = seed + 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
 uint32_t lds_bytes_per_wave(uint32_t stack_cap) { return static_cast<uint32_t>(kQueueFloats * 4 + 8u * stack_cap * 8u); }
 
 int check(hipError_t e, const char* what, std::string& err) {
@@ -1400,7 +1471,7 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     P.gen.jitter_scale = uniform_inclusive_scale(-0.5f, 0.5f);
     P.gen.width = L.width;
     P.gen.spp = L.spp;
-    P.gen.seed = L.seed;
+    P.gen.seed = mixed_seed(L.seed);
     P.tiles = L.d_tiles;
     P.n_tiles = L.n_tiles;
     P.tile_size = L.tile_size;
@@ -1411,6 +1482,7 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     P.s_end = L.pass_end;
     P.carry_in = L.carry_in ? 1u : 0u;
     P.finalize = L.finalize ? 1u : 0u;
+    P.chunked = L.chunked ? 1u : 0u;
     P.tile_order = L.d_tile_order;
     P.tile_cost = L.d_tile_cost;
     P.max_depth = L.max_depth;
@@ -1482,12 +1554,13 @@ int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::stri
     P.gen.jitter_scale = uniform_inclusive_scale(-0.5f, 0.5f);
     P.gen.width = L.width;
     P.gen.spp = L.spp;
-    P.gen.seed = L.seed;
+    P.gen.seed = mixed_seed(L.seed);
     P.tile_size = L.tile_size;
     P.max_depth = L.max_depth;
     P.out = L.d_out;
     P.inv_spp = 1.0f / static_cast<float>(L.spp);
     P.segments = L.d_segments;
+    P.chunked = L.chunked ? 1u : 0u;
     const bool lds_stack = L.scene.stack_cap > L.scene.packet_stack_regs;
     P.lds_per_wave = lds_stack ? ((L.scene.stack_cap - L.scene.packet_stack_regs) * 20u + 15u) & ~15u : 0u;
     const uint32_t plds = P.lds_per_wave * 4;
@@ -1601,7 +1674,7 @@ int launch_generate_rays(const mp_camera_sampler& s, uint32_t width, uint32_t sp
     G.jitter_scale = uniform_inclusive_scale(-0.5f, 0.5f);
     G.width = width;
     G.spp = spp;
-    G.seed = seed;
+    G.seed = mixed_seed(seed);
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 8192));
     hipLaunchKernelGGL(generate_rays_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), G, block, sample, ox,
                        oy, oz, dx, dy, dz);

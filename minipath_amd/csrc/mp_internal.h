@@ -43,16 +43,22 @@ struct HostBvh {
     std::vector<TriPacketRef> packets;
     std::vector<Box3> packet_box;         // enclosing (leaf) box of each packet
     std::vector<TriShadingRef> shading;   // packets*8
+    std::vector<uint32_t> material;       // packets*8 : TriangleShadingData.material (mod.rs:44); 0 for padding
     std::vector<float> vnormal, vtex;     // nv*3
     uint32_t vertex_count = 0;
+    std::vector<std::string> material_names;  // [0] = "" (faces before any usemtl), then `usemtl` names in first-seen order
 };
 
-// building.rs:83-107.  Returns MP_OK or an error code with `err` filled.
-int build_bvh(const float* pos, const float* nrm, const float* tex, uint32_t nv, const uint32_t* tri, uint32_t nt,
-              HostBvh& out, std::string& err);
-// building.rs:28-81
+// building.rs:83-107.  Returns MP_OK or an error code with `err` filled.  tri_mat (nullable): material id per input triangle
+// (the reference writes `material: 0`, building.rs:201).
+int build_bvh(const float* pos, const float* nrm, const float* tex, uint32_t nv, const uint32_t* tri, const uint32_t* tri_mat,
+              uint32_t nt, HostBvh& out, std::string& err);
+// building.rs:28-81 (+ `usemtl` -> per-triangle material ids, which the reference ignores)
 int load_obj(const char* path, std::vector<float>& pos, std::vector<float>& nrm, std::vector<float>& tex,
-             std::vector<uint32_t>& tri, std::string& err);
+             std::vector<uint32_t>& tri, std::vector<uint32_t>& tri_mat, std::vector<std::string>& material_names, std::string& err);
+// A TriangleBvh handed over as its reference-layout arrays (mp_scene_from_arrays): validates the links, recomputes the box
+// chain, depth and triangle count.
+int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err);
 
 // ---- device scene ("traversal format") -------------------------------------------------------
 // nodes_aos : inner_count x 8 children x 8 dwords {minx,miny,minz,maxx,maxy,maxz,link,0}: absolute decompressed child boxes.
@@ -61,7 +67,7 @@ int load_obj(const char* path, std::vector<float>& pos, std::vector<float>& nrm,
 //             The packet walk reads both through the scalar unit (wave-uniform), the 8-lane-group walk as one 16-byte word per
 //             lane (lane i = child i / triangle i).
 // pkt_valid : real (unpadded) triangles of each packet.
-// shade     : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) pad pad.  48 B per triangle slot.
+// shade     : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) material(u32 bits) pad.  48 B per triangle slot.
 // vidx/vtex : for the full HitRecord (texture_coords).
 struct DevScene {
     uint32_t kind = 0;               // 0 = TriangleBvh, 1 = Sphere (scene/primitives.rs:10-13)
@@ -73,6 +79,8 @@ struct DevScene {
     const uint32_t* pkt_valid = nullptr;
     const uint32_t* vidx = nullptr;  // packets*8*3
     const float* vtex = nullptr;     // nv*3
+    const float* materials = nullptr;  // build-defined path extension: {albedo, emission} per material id (device)
+    float sky = 1.0f;                  // ... and the sky radiance
     uint32_t root = MP_LINK_NULL;
     uint32_t inner_count = 0;
     uint32_t packet_count = 0;
@@ -111,6 +119,7 @@ struct RenderLaunch {
     // sums of the earlier passes; finalize: write means (worker.rs:44) instead of sums
     uint32_t pass_begin = 0, pass_end = 0;
     bool carry_in = false, finalize = true;
+    bool chunked = false;         // MP_FLAG_CHUNKED_SUM
     uint32_t packet_samples = 0;  // samples of a pixel in flight per pass of the packet kernel (0 = automatic)
     const uint32_t* d_tile_order = nullptr;      // optional: hand-out order of the tiles (device, n_tiles)
     unsigned long long* d_tile_cost = nullptr;   // optional: += shader-clock cycles spent per tile (device, n_tiles)

@@ -64,7 +64,7 @@ inline float dequantise_coord(uint16_t q, float size, float mn) {
     return std::fmaf(size, static_cast<float>(static_cast<int32_t>(q)) * kInvU16Max, mn);
 }
 
-struct Tri { uint32_t v[3]; };
+struct Tri { uint32_t v[3]; uint32_t mat; };  // mat: TriangleShadingData.material (0 in the reference, building.rs:201)
 
 inline void extend(Box3& b, const float* p) {  // aabb.rs:219-222
     for (int k = 0; k < 3; k++) {
@@ -98,6 +98,7 @@ struct Fragment {
     std::vector<TriPacketRef> packets;
     std::vector<Box3> packet_box;
     std::vector<TriShadingRef> shading;
+    std::vector<uint32_t> material;
     uint32_t depth = 0;  // inner levels below (and including) this subtree's root
     uint32_t root = MP_LINK_NULL;
 };
@@ -138,6 +139,7 @@ class Builder {
         out.packets = std::move(f.packets);
         out.packet_box = std::move(f.packet_box);
         out.shading = std::move(f.shading);
+        out.material = std::move(f.material);
         return true;
     }
 
@@ -360,6 +362,7 @@ class Builder {
                     }
                 }
                 f.shading.push_back(sh);
+                f.material.push_back(mask ? tris[ti].mat : 0u);
             }
             f.packets.push_back(pk);
             f.packet_box.push_back(enc);
@@ -433,6 +436,7 @@ class Builder {
             f.packets.insert(f.packets.end(), c.packets.begin(), c.packets.end());
             f.packet_box.insert(f.packet_box.end(), c.packet_box.begin(), c.packet_box.end());
             f.shading.insert(f.shading.end(), c.shading.begin(), c.shading.end());
+            f.material.insert(f.material.end(), c.material.begin(), c.material.end());
             f.depth = std::max(f.depth, c.depth);
         }
         f.depth += 1;
@@ -443,8 +447,8 @@ class Builder {
 
 }  // namespace
 
-int build_bvh(const float* pos, const float* nrm, const float* tex, uint32_t nv, const uint32_t* tri, uint32_t nt,
-              HostBvh& out, std::string& err) {
+int build_bvh(const float* pos, const float* nrm, const float* tex, uint32_t nv, const uint32_t* tri, const uint32_t* tri_mat,
+              uint32_t nt, HostBvh& out, std::string& err) {
     out = HostBvh{};
     if (nt == 0) { err = "no triangles (reference panics in build_leaf, building.rs:178)"; return MP_ERR_BUILD; }
     if (!pos || !tri) { err = "null positions/indices"; return MP_ERR_INVALID; }
@@ -456,9 +460,94 @@ int build_bvh(const float* pos, const float* nrm, const float* tex, uint32_t nv,
     if (nrm) std::memcpy(out.vnormal.data(), nrm, static_cast<size_t>(nv) * 12);
     if (tex) std::memcpy(out.vtex.data(), tex, static_cast<size_t>(nv) * 12);
     std::vector<Tri> tris(nt);
-    std::memcpy(tris.data(), tri, static_cast<size_t>(nt) * sizeof(Tri));
+    for (size_t i = 0; i < nt; i++) tris[i] = Tri{{tri[3 * i], tri[3 * i + 1], tri[3 * i + 2]}, tri_mat ? tri_mat[i] : 0u};
     Builder b(pos, out.vnormal.data(), nt, err);
     if (!b.run(tris, out)) return MP_ERR_BUILD;
+    return MP_OK;
+}
+
+// ---- import of reference-layout arrays (mp_scene_from_arrays) ----------------------------------------------------------
+// The box chain of SURVEY A.4 is a pure function of the arrays: child i of a node with enclosing box {mn, size} has
+// {fma(size, q_min/65535, mn), fma(size, q_max/65535, mn)} (ray_bvh_intersection.rs:155-157), leaves inherit their entry's box.
+int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err) {
+    out = HostBvh{};
+    if ((d.inner_count && !d.inner_nodes) || (d.packet_count && (!d.packets || !d.tri_shading))) { err = "NULL array"; return MP_ERR_INVALID; }
+    if (d.vertex_count && !d.vertex_normals) { err = "NULL vertex normals"; return MP_ERR_INVALID; }
+    if (d.inner_count > kMaxIndex || d.packet_count > kMaxIndex) { err = "more nodes/packets than a CompressedNodeLink can address (mod.rs:66)"; return MP_ERR_INVALID; }
+    const size_t ni = d.inner_count, np = d.packet_count;
+    out.inner.resize(ni);
+    out.packets.resize(np);
+    out.shading.resize(np * 8);
+    out.material.assign(np * 8, 0u);
+    if (ni) std::memcpy(out.inner.data(), d.inner_nodes, ni * sizeof(InnerNodeRef));
+    if (np) std::memcpy(out.packets.data(), d.packets, np * sizeof(TriPacketRef));
+    if (np) std::memcpy(out.shading.data(), d.tri_shading, np * 8 * sizeof(TriShadingRef));
+    if (np && d.tri_material) std::memcpy(out.material.data(), d.tri_material, np * 8 * sizeof(uint32_t));
+    out.vertex_count = d.vertex_count;
+    out.vnormal.assign(static_cast<size_t>(d.vertex_count) * 3, 0.0f);
+    out.vtex.assign(static_cast<size_t>(d.vertex_count) * 3, 0.0f);
+    if (d.vertex_count) std::memcpy(out.vnormal.data(), d.vertex_normals, static_cast<size_t>(d.vertex_count) * 12);
+    if (d.vertex_count && d.vertex_tex) std::memcpy(out.vtex.data(), d.vertex_tex, static_cast<size_t>(d.vertex_count) * 12);
+    for (int k = 0; k < 3; k++) { out.bbox.mn[k] = d.bbox_min[k]; out.bbox.mx[k] = d.bbox_max[k]; }
+    out.root = d.root_link;
+    out.material_names.assign(1, std::string());
+    for (const TriShadingRef& sh : out.shading)
+        for (int v = 0; v < 3; v++)
+            if (sh.vi[v] >= std::max<uint32_t>(d.vertex_count, 1u)) { err = "vertex index out of range in tri_shading"; return MP_ERR_INVALID; }
+    out.inner_box.assign(ni, Box3{});
+    out.packet_box.assign(np, Box3{});
+    std::vector<uint8_t> inner_seen(ni, 0), packet_seen(np, 0);
+    struct Item { uint32_t link; Box3 box; uint32_t level; };
+    std::vector<Item> todo;
+    todo.push_back({d.root_link, out.bbox, 0});
+    uint32_t depth = 0;
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        if (it.link == MP_LINK_NULL) continue;
+        const uint32_t idx = it.link >> 3, cnt = it.link & 7u;
+        if (cnt != 0) {  // leaf: cnt consecutive packets
+            if (static_cast<size_t>(idx) + cnt > np) { err = "leaf link outside the packet array"; return MP_ERR_INVALID; }
+            for (uint32_t p = idx; p < idx + cnt; p++) {
+                if (packet_seen[p]) { err = "packet referenced by two leaves"; return MP_ERR_INVALID; }
+                packet_seen[p] = 1;
+                out.packet_box[p] = it.box;
+            }
+            continue;
+        }
+        if (idx >= ni) { err = "inner link outside the node array"; return MP_ERR_INVALID; }
+        if (inner_seen[idx]) { err = "inner node referenced twice (not a tree)"; return MP_ERR_INVALID; }
+        inner_seen[idx] = 1;
+        out.inner_box[idx] = it.box;
+        depth = std::max(depth, it.level + 1);
+        float size[3];
+        for (int k = 0; k < 3; k++) size[k] = it.box.mx[k] - it.box.mn[k];
+        const InnerNodeRef& nd = out.inner[idx];
+        for (int i = 0; i < 8; i++) {
+            if (nd.link[i] == MP_LINK_NULL) continue;
+            // the device walk numbers stack slots by node order: children must follow their parent (pre-order, as the builder emits)
+            if ((nd.link[i] & 7u) == 0u && (nd.link[i] >> 3) <= idx) { err = "inner nodes are not in pre-order (child index <= parent index)"; return MP_ERR_INVALID; }
+            Box3 cb;
+            for (int k = 0; k < 3; k++) {
+                cb.mn[k] = dequantise_coord(nd.bmin[k][i], size[k], it.box.mn[k]);
+                cb.mx[k] = dequantise_coord(nd.bmax[k][i], size[k], it.box.mn[k]);
+            }
+            todo.push_back({nd.link[i], cb, it.level + 1});
+        }
+    }
+    out.depth = depth;
+    // real (unpadded) triangles: padding = all-zero quantised vertices with default shading at the tail of a leaf's last packet
+    uint32_t real = 0;
+    for (size_t p = 0; p < np; p++)
+        for (int i = 0; i < 8; i++) {
+            bool pad = true;
+            for (int a = 0; a < 3 && pad; a++)
+                for (int k = 0; k < 3; k++)
+                    if (out.packets[p].v[a][k][i] != 0) { pad = false; break; }
+            const TriShadingRef& sh = out.shading[p * 8 + i];
+            if (!(pad && sh.vi[0] == 0 && sh.vi[1] == 0 && sh.vi[2] == 0 && sh.flat == 0)) real++;
+        }
+    out.triangle_count = real;
     return MP_OK;
 }
 
@@ -500,12 +589,14 @@ bool parse_tuple(const char* s, size_t np, size_t nt, size_t nn, Key& k) {
 }  // namespace
 
 int load_obj(const char* path, std::vector<float>& pos, std::vector<float>& nrm, std::vector<float>& tex,
-             std::vector<uint32_t>& tri, std::string& err) {
+             std::vector<uint32_t>& tri, std::vector<uint32_t>& tri_mat, std::vector<std::string>& material_names, std::string& err) {
     FILE* f = std::fopen(path, "r");
     if (!f) { err = std::string("Failed to read file: ") + path; return MP_ERR_IO; }
     std::vector<float> P, T, N;
     std::unordered_map<Key, uint32_t, KeyHash> seen;
-    pos.clear(); nrm.clear(); tex.clear(); tri.clear();
+    pos.clear(); nrm.clear(); tex.clear(); tri.clear(); tri_mat.clear();
+    material_names.assign(1, std::string());  // id 0: faces before any `usemtl` (the reference's `material: 0`)
+    uint32_t cur_mat = 0;
     char* line = nullptr;
     size_t cap = 0;
     bool bad = false;
@@ -522,6 +613,19 @@ int load_obj(const char* path, std::vector<float>& pos, std::vector<float>& nrm,
         } else if (s[0] == 'v' && s[1] == 't' && is_ws(s[2])) {
             char* e = s + 2;
             for (int k = 0; k < 2; k++) T.push_back(std::strtof(e, &e));
+        } else if (std::strncmp(s, "usemtl", 6) == 0 && is_ws(s[6])) {
+            // ids in first-seen order of the names, from 1 (the reference ignores usemtl: ids only feed the build-defined extension)
+            char* nm = s + 6;
+            while (is_ws(*nm)) nm++;
+            std::string name(nm);
+            while (!name.empty() && (name.back() == '\n' || name.back() == '\r' || is_ws(name.back()))) name.pop_back();
+            auto it = std::find(material_names.begin() + 1, material_names.end(), name);
+            if (it == material_names.end()) {
+                material_names.push_back(name);
+                cur_mat = static_cast<uint32_t>(material_names.size() - 1);
+            } else {
+                cur_mat = static_cast<uint32_t>(it - material_names.begin());
+            }
         } else if (s[0] == 'f' && is_ws(s[1])) {
             Key keys[4];
             int nv = 0;
@@ -551,6 +655,7 @@ int load_obj(const char* path, std::vector<float>& pos, std::vector<float>& nrm,
                 } else idx = it->second;
                 tri.push_back(idx);
             }
+            tri_mat.push_back(cur_mat);
         }
     }
     std::free(line);

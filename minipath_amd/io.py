@@ -60,12 +60,13 @@ def save_pfm(path: str, rgb_f32: np.ndarray) -> None:
 
 
 # ---- checkpoint / resume of a progressive render (SURVEY "aux subsystems": the reference has none; BASELINE configs[4]) ----
-_CKPT_KEYS = ("tile_size", "sample_count", "width", "height", "seed", "max_depth")
+_CKPT_KEYS = ("tile_size", "sample_count", "width", "height", "seed", "max_depth", "chunked_sum")
 
 
 def _settings_key(settings) -> np.ndarray:
     w, h = settings.resolution
-    return np.array([settings.tile_size, settings.sample_count, w, h, int(settings.seed) & 0xFFFFFFFFFFFFFFFF, settings.max_depth],
+    return np.array([settings.tile_size, settings.sample_count, w, h, int(settings.seed) & 0xFFFFFFFFFFFFFFFF, settings.max_depth,
+                     1 if getattr(settings, "chunked_sum", False) else 0],
                     dtype=np.uint64)
 
 

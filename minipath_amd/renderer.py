@@ -26,6 +26,7 @@ class RenderSettings:
     traversal: str = "packets"  # "packets": 64 camera rays per wave share one BVH walk; "groups": 8 lanes per ray
     max_depth: int = 0  # 0: reference semantics (primary ray + |d.n|).  >= 1: build-defined path extension (MP_FLAG_PATHS)
     wavefront: bool = False  # with max_depth >= 1: staged evaluation, bounce rays sorted into packets (MP_FLAG_WAVEFRONT)
+    chunked_sum: bool = False  # build-defined: f32 sums over 256-sample chunks, f64 total (MP_FLAG_CHUNKED_SUM; configs[4])
 
     def as_struct(self) -> _lib.SettingsStruct:
         if self.tile_size <= 0 or self.sample_count <= 0:
@@ -38,7 +39,8 @@ class RenderSettings:
             (_lib.MP_FLAG_SHUFFLE_TILES if self.shuffle_tiles else 0)
             | (_lib.MP_FLAG_TRAVERSAL_GROUPS if self.traversal == "groups" else 0)
             | (_lib.MP_FLAG_PATHS if self.max_depth > 0 else 0)
-            | (_lib.MP_FLAG_WAVEFRONT if (self.wavefront and self.max_depth > 0) else 0),
+            | (_lib.MP_FLAG_WAVEFRONT if (self.wavefront and self.max_depth > 0) else 0)
+            | (_lib.MP_FLAG_CHUNKED_SUM if self.chunked_sum else 0),
             int(self.max_depth),
             0,
             0,

@@ -55,21 +55,55 @@ class TriangleBvh:
         return cls(h, ctx)
 
     @classmethod
-    def build(cls, positions, normals, tex, triangles, ctx: Optional[Context] = None) -> "TriangleBvh":
-        """TriangleBvh::build (building.rs:83-107) over indexed triangles."""
+    def build(cls, positions, normals, tex, triangles, ctx: Optional[Context] = None, tri_material=None) -> "TriangleBvh":
+        """TriangleBvh::build (building.rs:83-107) over indexed triangles.  tri_material: optional material id per triangle
+        (the reference writes `material: 0`, building.rs:201)."""
         pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
         nv = pos.shape[0]
         nrm = None if normals is None else np.ascontiguousarray(normals, np.float32).reshape(nv, 3)
         tx = None if tex is None else np.ascontiguousarray(tex, np.float32).reshape(nv, 3)
         tri = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        mat = None if tri_material is None else np.ascontiguousarray(tri_material, np.uint32).reshape(tri.shape[0])
         h = C.c_void_p()
         _lib.check(
-            _lib.lib().mp_scene_from_triangles(
+            _lib.lib().mp_scene_from_triangles_mat(
                 ctx.handle if ctx else None, pos.ctypes.data, nrm.ctypes.data if nrm is not None else None,
-                tx.ctypes.data if tx is not None else None, nv, tri.ctypes.data, tri.shape[0], C.byref(h),
+                tx.ctypes.data if tx is not None else None, nv, tri.ctypes.data, mat.ctypes.data if mat is not None else None,
+                tri.shape[0], C.byref(h),
             )
         )
         return cls(h, ctx)
+
+    @classmethod
+    def from_arrays(cls, inner, packets, shading, vertex_normals, vertex_tex, root_link, bbox_min, bbox_max,
+                    ctx: Optional[Context] = None, tri_material=None) -> "TriangleBvh":
+        """mp_scene_from_arrays: a TriangleBvh the caller already holds, in the reference's own layout
+        (triangle_bvh/mod.rs:20-53) -- the inverse of export().  Nothing is rebuilt: triangle_index values and the lane
+        order inside leaves are the caller's."""
+        inner = np.ascontiguousarray(inner, np.uint8).reshape(-1, 128)
+        packets = np.ascontiguousarray(packets, np.uint8).reshape(-1, 144)
+        shading = np.ascontiguousarray(shading, np.uint32).reshape(-1, 4)
+        vn = np.ascontiguousarray(vertex_normals, np.float32).reshape(-1, 3)
+        vt = None if vertex_tex is None else np.ascontiguousarray(vertex_tex, np.float32).reshape(-1, 3)
+        mat = None if tri_material is None else np.ascontiguousarray(tri_material, np.uint32).reshape(-1)
+        d = _lib.BvhDesc(
+            inner.ctypes.data, packets.ctypes.data, shading.ctypes.data, mat.ctypes.data if mat is not None else None,
+            vn.ctypes.data, vt.ctypes.data if vt is not None else None, inner.shape[0], packets.shape[0], vn.shape[0],
+            int(root_link), (C.c_float * 3)(*[float(x) for x in bbox_min]), (C.c_float * 3)(*[float(x) for x in bbox_max]),
+        )
+        h = C.c_void_p()
+        _lib.check(_lib.lib().mp_scene_from_arrays(ctx.handle if ctx else None, C.byref(d), C.byref(h)))
+        return cls(h, ctx)
+
+    def set_materials(self, table, sky: float = 1.0) -> None:
+        """Material table [(albedo, emission), ...] and sky radiance of the build-defined path extension."""
+        t = [(float(a), float(e)) for a, e in table]
+        arr = (_lib.Material * max(len(t), 1))(*[_lib.Material(a, e) for a, e in t])
+        _lib.check(_lib.lib().mp_scene_set_materials(self.handle, arr, len(t), C.c_float(sky)))
+
+    def material_name(self, i: int) -> Optional[str]:
+        n = _lib.lib().mp_scene_material_name(self.handle, int(i))
+        return None if n is None else n.decode()
 
     def info(self) -> _lib.SceneInfo:
         out = _lib.SceneInfo()
@@ -81,21 +115,23 @@ class TriangleBvh:
         i = self.info()
         return np.array(list(i.bbox_min), np.float32), np.array(list(i.bbox_max), np.float32)
 
-    def export(self):
+    def export(self, with_material: bool = False):
         """Reference-layout arrays: inner nodes (n,128) u8, packets (n,144) u8, tri shading (n*8,4) u32,
-        vertex normals / tex (nv,3) f32."""
+        vertex normals / tex (nv,3) f32 (+ material id per triangle slot (n*8,) u32 with with_material=True)."""
         i = self.info()
         inner = np.zeros((i.inner_count, 128), np.uint8)
         packets = np.zeros((i.packet_count, 144), np.uint8)
         shading = np.zeros((i.packet_count * 8, 4), np.uint32)
         vn = np.zeros((i.vertex_count, 3), np.float32)
         vt = np.zeros((i.vertex_count, 3), np.float32)
+        mat = np.zeros((i.packet_count * 8,), np.uint32)
         _lib.check(
             _lib.lib().mp_scene_export(
-                self.handle, inner.ctypes.data, packets.ctypes.data, shading.ctypes.data, vn.ctypes.data, vt.ctypes.data
+                self.handle, inner.ctypes.data, packets.ctypes.data, shading.ctypes.data, vn.ctypes.data, vt.ctypes.data,
+                mat.ctypes.data,
             )
         )
-        return inner, packets, shading, vn, vt
+        return (inner, packets, shading, vn, vt, mat) if with_material else (inner, packets, shading, vn, vt)
 
     def intersect(self, origins, directions, stream=None, full: bool = False):
         """impl Object for TriangleBvh::intersect (ray_bvh_intersection.rs:26-96), batched over CUDA/HIP tensors.
@@ -117,11 +153,13 @@ class TriangleBvh:
             "u": torch.empty(n, dtype=torch.float32, device=dev),
             "v": torch.empty(n, dtype=torch.float32, device=dev),
         }
-        hits = _lib.HitsSoA(out["t"].data_ptr(), out["prim"].data_ptr(), out["u"].data_ptr(), out["v"].data_ptr(), None, None, None)
+        hits = _lib.HitsSoA(out["t"].data_ptr(), out["prim"].data_ptr(), out["u"].data_ptr(), out["v"].data_ptr(), None, None, None, None)
         if full:
             for k in ("point", "normal", "tex"):
                 out[k] = torch.empty((n, 3), dtype=torch.float32, device=dev)
+            out["material"] = torch.empty(n, dtype=torch.int32, device=dev)
             hits.d_point, hits.d_normal, hits.d_tex = out["point"].data_ptr(), out["normal"].data_ptr(), out["tex"].data_ptr()
+            hits.d_material = out["material"].data_ptr()
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         _lib.check(
             _lib.lib().mp_trace_rays(

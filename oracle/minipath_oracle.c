@@ -107,9 +107,18 @@ void mpo_rng_unit_disc(mpo_rng *r, float out[2]) {
 }
 
 /* Build-defined seeded mode (the reference's RNG is OS-seeded, worker.rs:25):
- * key = seed + ((y*W + x)*spp + s), all u64 wrapping. */
+ *   key = mix(seed) + ((y*W + x)*spp + s), all u64 wrapping,  mix(seed) = the first SplitMix64 output for state `seed`
+ * (the value seed_from_u64(seed) puts into s[0]).  The seed is mixed before the sample index is added so that the streams of
+ * consecutive seeds are unrelated: with a plain `seed + index` the frame of seed s+1 would be the frame of seed s shifted by
+ * one sample.  A reference user reproduces it with SmallRng::seed_from_u64(key) at the top of render_sample (worker.rs:57). */
+uint64_t mpo_seed_mix(uint64_t seed) {
+    uint64_t z = seed + 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
 uint64_t mpo_sample_key(uint64_t seed, uint32_t width, uint32_t spp, uint32_t x, uint32_t y, uint32_t s) {
-    return seed + (((uint64_t)y * (uint64_t)width + (uint64_t)x) * (uint64_t)spp + (uint64_t)s);
+    return mpo_seed_mix(seed) + (((uint64_t)y * (uint64_t)width + (uint64_t)x) * (uint64_t)spp + (uint64_t)s);
 }
 
 /* ================================================================================================= */
@@ -513,6 +522,9 @@ size_t mpo_internal_points(uint32_t minx, uint32_t miny, uint32_t maxx, uint32_t
 /* building.rs                                                                                       */
 /* ================================================================================================= */
 
+#define MPO_PATH_ALBEDO 0.75f /* default material of the build-defined path extension */
+#define MPO_PATH_EPS 1e-4f
+
 struct mpo_bvh {
     float bbox_min[3], bbox_max[3];
     uint32_t root;
@@ -522,6 +534,10 @@ struct mpo_bvh {
     uint32_t cap_shading;
     float *vnormal, *vtex; uint32_t nv;
     uint32_t depth;
+    uint32_t *material;      /* n_packets*8 : TriangleShadingData.material (mod.rs:44), 0 for padding */
+    /* build-defined path extension: material table + sky radiance (see render_sample_paths_impl) */
+    mpo_material *mats; uint32_t n_mats;
+    float sky;
 };
 
 typedef struct { float mn[3], mx[3]; } box3;
@@ -555,7 +571,7 @@ static inline float box_surface_area(const box3 *b) { /* aabb.rs:247-251 */
 }
 
 /* triangle.rs:115-120 : sum of coords (fold from zero) / 3 */
-static inline void tri_centroid(const build_ctx *c, const uint32_t t[3], float out[3]) {
+static inline void tri_centroid(const build_ctx *c, const uint32_t t[4], float out[3]) {
     for (int k = 0; k < 3; k++) {
         float s = 0.0f + c->pos[3 * t[0] + k];
         s = s + c->pos[3 * t[1] + k];
@@ -600,7 +616,7 @@ static inline size_t bin_index(const bin_grid *g, const float p[3]) {
 typedef struct { size_t lo, hi; box3 box; } child_range;
 
 /* building.rs:238-345.  Returns number of children (<= 8), reorders tris[0..n). */
-static int split_triangles(build_ctx *c, uint32_t (*tris)[3], size_t n, child_range out[8]) {
+static int split_triangles(build_ctx *c, uint32_t (*tris)[4], size_t n, child_range out[8]) {
     box3 cb;
     float ctr[3];
     tri_centroid(c, tris[0], ctr);
@@ -694,7 +710,7 @@ static int split_triangles(build_ctx *c, uint32_t (*tris)[3], size_t n, child_ra
             while (j >= 0 && roots[j] > v) { roots[j + 1] = roots[j]; j--; }
             roots[j + 1] = v;
         }
-        uint32_t (*tmp)[3] = malloc(n * sizeof(*tmp));
+        uint32_t (*tmp)[4] = malloc(n * sizeof(*tmp));
         size_t w = 0;
         for (int j = 0; j < nroots; j++) {
             child_range *cr = &out[nchild];
@@ -721,10 +737,10 @@ static int split_triangles(build_ctx *c, uint32_t (*tris)[3], size_t n, child_ra
     return nchild;
 }
 
-static uint32_t build_recursive(build_ctx *c, uint32_t (*tris)[3], size_t n, const box3 *enc, uint32_t depth);
+static uint32_t build_recursive(build_ctx *c, uint32_t (*tris)[4], size_t n, const box3 *enc, uint32_t depth);
 
 /* building.rs:170-207 */
-static uint32_t build_leaf(build_ctx *c, uint32_t (*tris)[3], size_t n, const box3 *enc) {
+static uint32_t build_leaf(build_ctx *c, uint32_t (*tris)[4], size_t n, const box3 *enc) {
     mpo_bvh *b = c->bvh;
     if (n == 0) { set_err(c, "empty leaf (reference asserts !triangles.is_empty(), building.rs:178)"); return MPO_LINK_NULL; }
     float emin[3], esize[3];
@@ -735,6 +751,7 @@ static uint32_t build_leaf(build_ctx *c, uint32_t (*tris)[3], size_t n, const bo
         while (b->n_packets + packet_count > b->cap_packets) b->cap_packets = b->cap_packets ? b->cap_packets * 2 : 64;
         b->packets = realloc(b->packets, (size_t)b->cap_packets * sizeof(mpo_tri_packet));
         b->shading = realloc(b->shading, (size_t)b->cap_packets * 8 * sizeof(mpo_tri_shading));
+        b->material = realloc(b->material, (size_t)b->cap_packets * 8 * sizeof(uint32_t));
     }
     int ok = 1;
     uint32_t link = mpo_link_new_leaf(first, packet_count, &ok);
@@ -758,8 +775,11 @@ static uint32_t build_leaf(build_ctx *c, uint32_t (*tris)[3], size_t n, const bo
                     sh->vi[v] = tris[ti][v];
                 }
                 sh->flat = (uint32_t)flat;
+                /* the reference writes `material: 0` (:201); ids given by the caller / `usemtl` travel with the triangle */
+                b->material[(size_t)(first + p) * 8 + lane] = tris[ti][3];
             } else {
                 sh->vi[0] = sh->vi[1] = sh->vi[2] = 0; sh->flat = 0; /* Default :203-204 */
+                b->material[(size_t)(first + p) * 8 + lane] = 0;
             }
         }
     }
@@ -768,7 +788,7 @@ static uint32_t build_leaf(build_ctx *c, uint32_t (*tris)[3], size_t n, const bo
 }
 
 /* building.rs:122-168 */
-static uint32_t build_inner(build_ctx *c, uint32_t (*tris)[3], size_t n, const box3 *enc, uint32_t depth) {
+static uint32_t build_inner(build_ctx *c, uint32_t (*tris)[4], size_t n, const box3 *enc, uint32_t depth) {
     mpo_bvh *b = c->bvh;
     child_range ch[8];
     int nchild = split_triangles(c, tris, n, ch);
@@ -808,15 +828,12 @@ static uint32_t build_inner(build_ctx *c, uint32_t (*tris)[3], size_t n, const b
 }
 
 /* building.rs:109-120 */
-static uint32_t build_recursive(build_ctx *c, uint32_t (*tris)[3], size_t n, const box3 *enc, uint32_t depth) {
+static uint32_t build_recursive(build_ctx *c, uint32_t (*tris)[4], size_t n, const box3 *enc, uint32_t depth) {
     if (n <= MPO_LEAF_MAX_TRIANGLES) return build_leaf(c, tris, n, enc);
     return build_inner(c, tris, n, enc, depth);
 }
 
-/* building.rs:83-107 */
-mpo_bvh *mpo_bvh_build(const float *pos, const float *nrm, const float *tex, uint32_t nv, const uint32_t *tri_idx,
-                       uint32_t nt, char *err, size_t errcap) {
-    if (err && errcap) err[0] = 0;
+static mpo_bvh *bvh_alloc(uint32_t nv, const float *nrm, const float *tex) {
     mpo_bvh *b = calloc(1, sizeof(mpo_bvh));
     b->root = MPO_LINK_NULL;
     b->nv = nv;
@@ -824,12 +841,27 @@ mpo_bvh *mpo_bvh_build(const float *pos, const float *nrm, const float *tex, uin
     b->vtex = calloc((size_t)nv * 3 + 1, sizeof(float));
     if (nrm) memcpy(b->vnormal, nrm, (size_t)nv * 3 * sizeof(float));
     if (tex) memcpy(b->vtex, tex, (size_t)nv * 3 * sizeof(float));
+    b->mats = malloc(sizeof(mpo_material));
+    b->mats[0].albedo = MPO_PATH_ALBEDO; b->mats[0].emission = 0.0f;
+    b->n_mats = 1;
+    b->sky = 1.0f;
+    return b;
+}
+
+/* building.rs:83-107 ; tri_mat (nullable) = material id per input triangle (the reference has only material 0, :201) */
+mpo_bvh *mpo_bvh_build_mat(const float *pos, const float *nrm, const float *tex, uint32_t nv, const uint32_t *tri_idx,
+                           const uint32_t *tri_mat, uint32_t nt, char *err, size_t errcap) {
+    if (err && errcap) err[0] = 0;
+    mpo_bvh *b = bvh_alloc(nv, nrm, tex);
     build_ctx c = {pos, b->vnormal, nv, b, err, errcap, 0};
     for (uint32_t i = 0; i < nt * 3; i++)
         if (tri_idx[i] >= nv) { set_err(&c, "vertex index out of range"); mpo_bvh_free(b); return NULL; }
     if (nt == 0) { set_err(&c, "no triangles (reference panics in build_leaf, building.rs:178)"); mpo_bvh_free(b); return NULL; }
-    uint32_t (*tris)[3] = malloc((size_t)nt * sizeof(*tris));
-    memcpy(tris, tri_idx, (size_t)nt * sizeof(*tris));
+    uint32_t (*tris)[4] = malloc((size_t)nt * sizeof(*tris));
+    for (uint32_t i = 0; i < nt; i++) {
+        tris[i][0] = tri_idx[3 * i]; tris[i][1] = tri_idx[3 * i + 1]; tris[i][2] = tri_idx[3 * i + 2];
+        tris[i][3] = tri_mat ? tri_mat[i] : 0u;
+    }
     box3 bb;
     for (int k = 0; k < 3; k++) bb.mn[k] = bb.mx[k] = pos[3 * tris[0][0] + k];
     for (uint32_t i = 0; i < nt; i++)
@@ -841,9 +873,79 @@ mpo_bvh *mpo_bvh_build(const float *pos, const float *nrm, const float *tex, uin
     return b;
 }
 
+mpo_bvh *mpo_bvh_build(const float *pos, const float *nrm, const float *tex, uint32_t nv, const uint32_t *tri_idx,
+                       uint32_t nt, char *err, size_t errcap) {
+    return mpo_bvh_build_mat(pos, nrm, tex, nv, tri_idx, NULL, nt, err, errcap);
+}
+
+/* A TriangleBvh handed over as its reference-layout arrays (triangle_bvh/mod.rs:20-53): what a reference user's own tree holds.
+ * Arrays are copied.  `material` may be NULL (all 0, building.rs:201).  Links are validated so that traversal cannot leave the
+ * arrays; `depth` is recomputed. */
+static uint32_t arrays_depth(const mpo_bvh *b, uint32_t link, uint32_t level, int *ok) {
+    uint32_t index, count;
+    int kind = mpo_link_decode(link, &index, &count);
+    if (kind == 0) return 0;
+    if (kind == 2) { if ((uint64_t)index + count > b->n_packets) *ok = 0; return 0; }
+    if (index >= b->n_inner || level > 64) { *ok = 0; return 0; }
+    uint32_t d = 0;
+    for (int i = 0; i < 8 && *ok; i++) {
+        uint32_t l = b->inner[index].link[i];
+        if ((l & MPO_LINK_COUNT_MASK) == 0 && l != MPO_LINK_NULL && (l >> 3) <= index) { *ok = 0; break; } /* children follow parents */
+        uint32_t s = arrays_depth(b, l, level + 1, ok);
+        if (s > d) d = s;
+    }
+    return d + 1;
+}
+
+mpo_bvh *mpo_bvh_from_arrays(const mpo_inner_node *inner, uint32_t n_inner, const mpo_tri_packet *packets, uint32_t n_packets,
+                             const mpo_tri_shading *shading, const uint32_t *material, const float *vnormal, const float *vtex,
+                             uint32_t nv, uint32_t root, const float bmin[3], const float bmax[3], char *err, size_t errcap) {
+    if (err && errcap) err[0] = 0;
+    mpo_bvh *b = bvh_alloc(nv, vnormal, vtex);
+    b->n_inner = b->cap_inner = n_inner;
+    b->n_packets = b->cap_packets = n_packets;
+    b->inner = malloc(((size_t)n_inner + 1) * sizeof(mpo_inner_node));
+    b->packets = malloc(((size_t)n_packets + 1) * sizeof(mpo_tri_packet));
+    b->shading = malloc(((size_t)n_packets * 8 + 1) * sizeof(mpo_tri_shading));
+    b->material = calloc((size_t)n_packets * 8 + 1, sizeof(uint32_t));
+    if (n_inner) memcpy(b->inner, inner, (size_t)n_inner * sizeof(mpo_inner_node));
+    if (n_packets) memcpy(b->packets, packets, (size_t)n_packets * sizeof(mpo_tri_packet));
+    if (n_packets) memcpy(b->shading, shading, (size_t)n_packets * 8 * sizeof(mpo_tri_shading));
+    if (material && n_packets) memcpy(b->material, material, (size_t)n_packets * 8 * sizeof(uint32_t));
+    for (int k = 0; k < 3; k++) { b->bbox_min[k] = bmin[k]; b->bbox_max[k] = bmax[k]; }
+    b->root = root;
+    int ok = 1;
+    for (size_t i = 0; i < (size_t)n_packets * 8 && ok; i++)
+        for (int v = 0; v < 3; v++) if (b->shading[i].vi[v] >= (nv ? nv : 1u)) ok = 0;
+    if (ok) b->depth = arrays_depth(b, root, 0, &ok);
+    if (!ok) {
+        if (err && errcap) snprintf(err, errcap, "%s", "arrays do not form a TriangleBvh (link or vertex index out of range)");
+        mpo_bvh_free(b);
+        return NULL;
+    }
+    return b;
+}
+
+int mpo_bvh_set_materials(mpo_bvh *b, const mpo_material *table, uint32_t n, float sky) {
+    if (!b || !table || n == 0) return 0;
+    for (size_t i = 0; i < (size_t)b->n_packets * 8; i++) if (b->material[i] >= n) return 0;
+    free(b->mats);
+    b->mats = malloc((size_t)n * sizeof(mpo_material));
+    memcpy(b->mats, table, (size_t)n * sizeof(mpo_material));
+    b->n_mats = n;
+    b->sky = sky;
+    return 1;
+}
+const uint32_t *mpo_bvh_tri_material(const mpo_bvh *b) { return b->material; }
+uint32_t mpo_bvh_material_count(const mpo_bvh *b) {
+    uint32_t m = 0;
+    for (size_t i = 0; i < (size_t)b->n_packets * 8; i++) if (b->material[i] > m) m = b->material[i];
+    return m + 1;
+}
+
 void mpo_bvh_free(mpo_bvh *b) {
     if (!b) return;
-    free(b->inner); free(b->packets); free(b->shading); free(b->vnormal); free(b->vtex);
+    free(b->inner); free(b->packets); free(b->shading); free(b->vnormal); free(b->vtex); free(b->material); free(b->mats);
     free(b);
 }
 
@@ -896,7 +998,10 @@ mpo_bvh *mpo_bvh_from_obj(const char *path, char *err, size_t errcap) {
     if (!f) { if (err) snprintf(err, errcap, "Failed to read file: %s", path); return NULL; }
     fvec P = {0}, T = {0}, N = {0};
     fvec vpos = {0}, vnrm = {0}, vtex = {0};
-    uvec tri = {0};
+    uvec tri = {0}, tmat = {0};
+    /* `usemtl NAME`: material ids in first-seen order of the names, starting at 1; faces before any usemtl keep the
+     * reference's `material: 0` (building.rs:201 -- the reference ignores usemtl; ids feed the build-defined extension only) */
+    char **mnames = NULL; uint32_t n_mnames = 0, cur_mat = 0;
     size_t hcap = 1 << 12, hn = 0;
     vkey *ht = calloc(hcap, sizeof(vkey));
     char *line = NULL; size_t lcap = 0;
@@ -913,6 +1018,20 @@ mpo_bvh *mpo_bvh_from_obj(const char *path, char *err, size_t errcap) {
         } else if (s[0] == 'v' && s[1] == 't' && (s[2] == ' ' || s[2] == '\t')) {
             char *e = s + 2;
             for (int k = 0; k < 2; k++) fvec_push(&T, strtof(e, &e));
+        } else if (strncmp(s, "usemtl", 6) == 0 && (s[6] == ' ' || s[6] == '\t')) {
+            char *nm = s + 6;
+            while (*nm == ' ' || *nm == '\t') nm++;
+            size_t L = strlen(nm);
+            while (L > 0 && (nm[L - 1] == '\n' || nm[L - 1] == '\r' || nm[L - 1] == ' ' || nm[L - 1] == '\t')) nm[--L] = 0;
+            uint32_t id = 0;
+            for (uint32_t i = 0; i < n_mnames; i++) if (strcmp(mnames[i], nm) == 0) { id = i + 1; break; }
+            if (id == 0) {
+                mnames = realloc(mnames, ((size_t)n_mnames + 1) * sizeof(char *));
+                mnames[n_mnames] = malloc(L + 1);
+                memcpy(mnames[n_mnames], nm, L + 1);
+                id = ++n_mnames;
+            }
+            cur_mat = id;
         } else if (s[0] == 'f' && (s[1] == ' ' || s[1] == '\t')) {
             int64_t tup[64][3]; int nvtx = 0;
             char *save = NULL;
@@ -951,13 +1070,16 @@ mpo_bvh *mpo_bvh_from_obj(const char *path, char *err, size_t errcap) {
                 }
                 uvec_push(&tri, ht[h].index);
             }
+            uvec_push(&tmat, cur_mat);
         }
     }
     free(line);
     fclose(f);
     mpo_bvh *b = NULL;
     if (bad) { if (err) snprintf(err, errcap, "Failed to parse file: %s", path); }
-    else b = mpo_bvh_build(vpos.d, vnrm.d, vtex.d, (uint32_t)hn, tri.d, (uint32_t)(tri.n / 3), err, errcap);
+    else b = mpo_bvh_build_mat(vpos.d, vnrm.d, vtex.d, (uint32_t)hn, tri.d, tmat.d, (uint32_t)(tri.n / 3), err, errcap);
+    for (uint32_t i = 0; i < n_mnames; i++) free(mnames[i]);
+    free(mnames); free(tmat.d);
     free(P.d); free(T.d); free(N.d); free(vpos.d); free(vnrm.d); free(vtex.d); free(tri.d); free(ht);
     return b;
 }
@@ -1092,7 +1214,7 @@ static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache
     for (int k = 0; k < 3; k++) { out->gn[k] = best.gn[k]; out->tex[k] = tx[k]; }
     normalize3(n, out->normal);
     mpo_ray_point_at(ray, best.t, out->point);
-    out->material = 0;
+    out->material = b->material[best.prim]; /* always 0 in the reference (building.rs:201) */
 }
 
 size_t mpo_bvh_intersect_ops(const mpo_bvh *b, const mpo_ray *ray, uint8_t *ops, uint32_t *links, size_t cap) {
@@ -1203,17 +1325,18 @@ void mpo_render_tile_sphere(const float center[3], float radius, const mpo_sampl
 }
 
 /* ---- build-defined path extension (NO reference counterpart: the reference has no bounce loop) --------
- * Diffuse grey surfaces (albedo 0.75) under a uniform white sky, paths of at most max_depth segments:
- *   L = 0, throughput = 1; for depth = 1..max_depth: trace; miss -> L = throughput (sky radiance 1), stop;
- *   hit -> n = shading normal turned against the ray; throughput *= 0.75; at depth == max_depth stop (L stays 0);
+ * Diffuse grey surfaces with a material table {albedo, emission} indexed by TriangleShadingData.material (mod.rs:44; always 0
+ * in the reference, building.rs:201) under a uniform sky of radiance `sky`; defaults: one material {0.75, 0}, sky = 1.
+ * Paths of at most max_depth segments:
+ *   L = 0, throughput = 1; for depth = 1..max_depth: trace; miss -> L = L + throughput * sky, stop;
+ *   hit -> m = material of the triangle; L = L + throughput * emission[m]; n = shading normal turned against the ray;
+ *   throughput *= albedo[m]; at depth == max_depth stop;
  *   next direction = cosine-weighted about n: (x, y) = UnitDisc rejection sample from the SAME Xoshiro stream,
  *   z = sqrt(1 - (x*x + y*y)); orthonormal basis of Duff et al. 2017 (branchless, copysign); origin = point + n * 1e-4.
- * Only + - * / sqrt and comparisons, so the GPU reproduces it bit for bit.  rgba = (L, L, L, primary hit ? 1 : 0). */
+ * Only + - * / sqrt and comparisons, so the GPU reproduces it bit for bit.  rgba = (L, L, L, primary hit ? 1 : 0).
+ * With the defaults this is exactly the round-1 definition (L = 0 + throughput * 1 at the miss, + 0 at every hit). */
 static _Thread_local uint32_t g_max_depth = 0;      /* 0 = reference semantics (worker.rs:51-66) */
 static _Thread_local uint64_t g_segments = 0;
-
-#define MPO_PATH_ALBEDO 0.75f
-#define MPO_PATH_EPS 1e-4f
 
 static void render_sample_paths_impl(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t spp, uint64_t seed,
                                      uint32_t x, uint32_t y, uint32_t sample, uint32_t max_depth, stack_cache *st, float rgba[4],
@@ -1227,12 +1350,14 @@ static void render_sample_paths_impl(const mpo_bvh *b, const mpo_sampler *s, uin
         mpo_hit h;
         bvh_intersect_impl(b, &ray, st, &h, cnt);
         if (segments) (*segments)++;
-        if (!h.hit) { L = thr; break; }
+        if (!h.hit) { L = L + thr * b->sky; break; }
         if (depth == 1) alpha = 1.0f;
+        const mpo_material *m = &b->mats[h.material];
+        L = L + thr * m->emission;
         float n[3] = {h.normal[0], h.normal[1], h.normal[2]};
         float dn = ray.d[0] * n[0] + ray.d[1] * n[1] + ray.d[2] * n[2];
         if (dn > 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-        thr = thr * MPO_PATH_ALBEDO;
+        thr = thr * m->albedo;
         if (depth == max_depth) break;
         float d2[2];
         mpo_rng_unit_disc(&rng, d2);
@@ -1287,21 +1412,34 @@ void mpo_color_to_image(const float rgba[4], uint8_t out[4]) {
     }
 }
 
+/* BUILD-DEFINED accumulation rule for very long sample chains (BASELINE configs[4]: 65 536 spp; SURVEY 7 "hard parts"): the
+ * reference sums every sample of a pixel into one f32 (worker.rs:40-43), whose rounding error grows with the chain.  With the
+ * chunked rule the samples are summed in f32, in index order, in chunks of MPO_SUM_CHUNK (chunk c = samples
+ * [256c, 256c+256)), each chunk sum is added to an f64 total, and pixel = (f32)(total * (1.0 / (f64)spp)).  Off by default
+ * (reference semantics); process-wide switch, set before rendering. */
+#define MPO_SUM_CHUNK 256u
+static int g_chunked_sum = 0;
+void mpo_set_chunked_sum(int on) { g_chunked_sum = on; }
+
 static void render_tile_impl(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uint32_t spp, uint64_t seed,
                              uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, float *f32_out, size_t f32_row_stride,
                              uint8_t *u8_out, size_t u8_row_stride, stack_cache *st, mpo_counters *cnt) {
     float inv = 1.0f / (float)spp; /* :44 */
+    const double inv64 = 1.0 / (double)spp;
     for (uint32_t y = y0; y < y1; y++)
         for (uint32_t x = x0; x < x1; x++) { /* internal_points, x fastest :39 */
             float sum[4] = {0, 0, 0, 0};
+            double total[4] = {0, 0, 0, 0};
             for (uint32_t i = 0; i < spp; i++) { /* :41-43 */
                 float c[4];
                 if (g_max_depth == 0) { render_sample_impl(b, s, width, spp, seed, x, y, i, st, c, cnt); g_segments++; }
                 else render_sample_paths_impl(b, s, width, spp, seed, x, y, i, g_max_depth, st, c, cnt, &g_segments);
                 for (int k = 0; k < 4; k++) sum[k] += c[k];
+                if (g_chunked_sum && ((i + 1) % MPO_SUM_CHUNK == 0 || i + 1 == spp))
+                    for (int k = 0; k < 4; k++) { total[k] += (double)sum[k]; sum[k] = 0.0f; }
             }
             float px[4];
-            for (int k = 0; k < 4; k++) px[k] = sum[k] * inv;
+            for (int k = 0; k < 4; k++) px[k] = g_chunked_sum ? (float)(total[k] * inv64) : sum[k] * inv;
             size_t lx = x - x0, ly = y - y0;
             if (f32_out) memcpy(f32_out + ly * f32_row_stride + lx * 4, px, 16);
             if (u8_out) mpo_color_to_image(px, u8_out + ly * u8_row_stride + lx * 4);

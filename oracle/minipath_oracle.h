@@ -103,12 +103,16 @@ typedef struct {
 
 typedef struct mpo_bvh mpo_bvh;
 
+/* build-defined path extension: grey diffuse material {albedo, emission}, indexed by TriangleShadingData.material */
+typedef struct { float albedo, emission; } mpo_material;
+
 /* ---- RNG (R): rand 0.9.3 / rand_distr 0.5.1 ------------------------------------------------------- */
 void mpo_rng_seed(mpo_rng *r, uint64_t state);          /* Xoshiro256PlusPlus::seed_from_u64 (SplitMix64) */
 uint64_t mpo_rng_next_u64(mpo_rng *r);
 uint32_t mpo_rng_next_u32(mpo_rng *r);                  /* upper 32 bits of next_u64 */
 float mpo_rng_range_pm_half(mpo_rng *r);                /* rng.random_range(-0.5..=0.5), camera.rs:178-179 */
 void mpo_rng_unit_disc(mpo_rng *r, float out[2]);       /* rand_distr::UnitDisc, camera.rs:184 */
+uint64_t mpo_seed_mix(uint64_t seed);                  /* first SplitMix64 output for state `seed` */
 uint64_t mpo_sample_key(uint64_t seed, uint32_t width, uint32_t spp, uint32_t x, uint32_t y, uint32_t s);
 
 /* ---- geometry ------------------------------------------------------------------------------------- */
@@ -155,6 +159,17 @@ size_t mpo_internal_points(uint32_t minx, uint32_t miny, uint32_t maxx, uint32_t
 mpo_bvh *mpo_bvh_from_obj(const char *path, char *err, size_t errcap);                     /* :28-81 */
 mpo_bvh *mpo_bvh_build(const float *pos, const float *nrm, const float *tex, uint32_t nv,
                        const uint32_t *tri_idx, uint32_t nt, char *err, size_t errcap);     /* :83-207 */
+/* same with a material id per input triangle (nullable = all 0, the reference's `material: 0`, building.rs:201) */
+mpo_bvh *mpo_bvh_build_mat(const float *pos, const float *nrm, const float *tex, uint32_t nv, const uint32_t *tri_idx,
+                           const uint32_t *tri_mat, uint32_t nt, char *err, size_t errcap);
+/* a TriangleBvh given as its reference-layout arrays (triangle_bvh/mod.rs:20-53); arrays are copied, links validated */
+mpo_bvh *mpo_bvh_from_arrays(const mpo_inner_node *inner, uint32_t n_inner, const mpo_tri_packet *packets, uint32_t n_packets,
+                             const mpo_tri_shading *shading, const uint32_t *material, const float *vnormal, const float *vtex,
+                             uint32_t nv, uint32_t root, const float bmin[3], const float bmax[3], char *err, size_t errcap);
+/* material table + sky radiance of the build-defined path extension; returns 0 if a triangle's id is >= n */
+int mpo_bvh_set_materials(mpo_bvh *b, const mpo_material *table, uint32_t n, float sky);
+const uint32_t *mpo_bvh_tri_material(const mpo_bvh *b);       /* packet_count*8 entries */
+uint32_t mpo_bvh_material_count(const mpo_bvh *b);            /* max id + 1 */
 void mpo_bvh_free(mpo_bvh *b);
 uint32_t mpo_bvh_root(const mpo_bvh *b);
 void mpo_bvh_bbox(const mpo_bvh *b, float bmin[3], float bmax[3]);
@@ -186,6 +201,9 @@ void mpo_render_tile(const mpo_bvh *b, const mpo_sampler *s, uint32_t width, uin
                      uint64_t seed, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, float *rgba_f32,
                      uint8_t *rgba_u8, mpo_counters *cnt);
 void mpo_color_to_image(const float rgba[4], uint8_t out[4]); /* worker.rs:69-76 */
+/* BUILD-DEFINED (no reference counterpart): chunked accumulation for very long sample chains -- f32 sums over chunks of 256
+ * consecutive samples, chunk sums added in f64, pixel = (f32)(total * (1.0 / (f64)spp)).  Process-wide, off by default. */
+void mpo_set_chunked_sum(int on);
 /* renderer/machinery.rs:20-123 -- threads pulling tiles from an atomic queue.  Image-major f32/u8 output.
  * max_tiles = 0 renders all tiles, otherwise only the first max_tiles of the row-major order (bounded
  * baseline sample).  Returns wall seconds of the tile loop; *rays_out = samples rendered. */

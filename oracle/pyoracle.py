@@ -144,6 +144,20 @@ def lib() -> C.CDLL:
     L.mpo_bvh_from_obj.restype = C.c_void_p
     L.mpo_bvh_build.argtypes = [f32p, f32p, f32p, C.c_uint32, u32p, C.c_uint32, C.c_char_p, C.c_size_t]
     L.mpo_bvh_build.restype = C.c_void_p
+    L.mpo_bvh_build_mat.argtypes = [f32p, f32p, f32p, C.c_uint32, u32p, u32p, C.c_uint32, C.c_char_p, C.c_size_t]
+    L.mpo_bvh_build_mat.restype = C.c_void_p
+    L.mpo_bvh_from_arrays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, u32p, f32p, f32p, C.c_uint32,
+                                      C.c_uint32, f32p, f32p, C.c_char_p, C.c_size_t]
+    L.mpo_bvh_from_arrays.restype = C.c_void_p
+    L.mpo_bvh_set_materials.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_float]
+    L.mpo_bvh_set_materials.restype = C.c_int
+    L.mpo_bvh_tri_material.argtypes = [C.c_void_p]
+    L.mpo_bvh_tri_material.restype = C.c_void_p
+    L.mpo_bvh_material_count.argtypes = [C.c_void_p]
+    L.mpo_bvh_material_count.restype = C.c_uint32
+    L.mpo_set_chunked_sum.argtypes = [C.c_int]
+    L.mpo_seed_mix.argtypes = [C.c_uint64]
+    L.mpo_seed_mix.restype = C.c_uint64
     L.mpo_bvh_free.argtypes = [C.c_void_p]
     for name in ("root", "inner_count", "packet_count", "vertex_count", "depth"):
         fn = getattr(L, f"mpo_bvh_{name}")
@@ -274,20 +288,54 @@ class Bvh:
         return cls(h)
 
     @classmethod
-    def build(cls, pos, nrm, tex, tri) -> "Bvh":
+    def build(cls, pos, nrm, tex, tri, tri_material=None) -> "Bvh":
         pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
         nv = pos.shape[0]
         nrm = None if nrm is None else np.ascontiguousarray(nrm, np.float32).reshape(nv, 3)
         tex = None if tex is None else np.ascontiguousarray(tex, np.float32).reshape(nv, 3)
         tri = np.ascontiguousarray(tri, np.uint32).reshape(-1, 3)
+        mat = None if tri_material is None else np.ascontiguousarray(tri_material, np.uint32).reshape(tri.shape[0])
         err = C.create_string_buffer(512)
-        h = lib().mpo_bvh_build(
+        h = lib().mpo_bvh_build_mat(
             _f32p(pos), None if nrm is None else _f32p(nrm), None if tex is None else _f32p(tex), nv,
-            _u32p(tri), tri.shape[0], err, 512,
+            _u32p(tri), None if mat is None else _u32p(mat), tri.shape[0], err, 512,
         )
         if not h:
             raise RuntimeError(err.value.decode())
         return cls(h)
+
+    @classmethod
+    def from_arrays(cls, inner, packets, shading, vnormal, vtex, root, bmin, bmax, material=None) -> "Bvh":
+        """A TriangleBvh given as its reference-layout arrays (what mp_scene_export emits / mp_scene_from_arrays takes):
+        inner (n,128) u8, packets (n,144) u8, shading (n*8,4) u32, vertex normals / tex (nv,3) f32, material (n*8) u32."""
+        inner = np.ascontiguousarray(inner, np.uint8).reshape(-1, 128)
+        packets = np.ascontiguousarray(packets, np.uint8).reshape(-1, 144)
+        shading = np.ascontiguousarray(shading, np.uint32).reshape(-1, 4)
+        vn = np.ascontiguousarray(vnormal, np.float32).reshape(-1, 3)
+        vt = np.ascontiguousarray(vtex, np.float32).reshape(-1, 3)
+        mat = None if material is None else np.ascontiguousarray(material, np.uint32).reshape(-1)
+        bmin = np.ascontiguousarray(bmin, np.float32)
+        bmax = np.ascontiguousarray(bmax, np.float32)
+        err = C.create_string_buffer(512)
+        h = lib().mpo_bvh_from_arrays(inner.ctypes.data, inner.shape[0], packets.ctypes.data, packets.shape[0], shading.ctypes.data,
+                                      None if mat is None else _u32p(mat), _f32p(vn), _f32p(vt), vn.shape[0], int(root),
+                                      _f32p(bmin), _f32p(bmax), err, 512)
+        if not h:
+            raise RuntimeError(err.value.decode())
+        return cls(h)
+
+    def set_materials(self, table, sky: float = 1.0) -> None:
+        """Material table [(albedo, emission), ...] + sky radiance of the build-defined path extension."""
+        t = np.ascontiguousarray(table, np.float32).reshape(-1, 2)
+        if not lib().mpo_bvh_set_materials(self.h, _f32p(t), t.shape[0], C.c_float(sky)):
+            raise RuntimeError("material id of a triangle outside the table")
+
+    def tri_material(self) -> np.ndarray:
+        return self._view(lib().mpo_bvh_tri_material(self.h), self.n_packets * 8 * 4, np.uint32).copy()
+
+    @property
+    def material_count(self) -> int:
+        return lib().mpo_bvh_material_count(self.h)
 
     def __del__(self):
         try:

@@ -93,3 +93,65 @@ def test_oracle_traversal_matches_brute_force(oracle, teapot_oracle_bvh):
             assert abs(tb - t_oracle[i]) <= 2e-5 * max(1.0, tb), (i, tb, t_oracle[i])
             agree += 1
     assert agree >= 396  # silhouette rays may flip between f32 and f64
+
+
+def test_chunked_sum_rule_is_close_to_the_single_chain(oracle, teapot_oracle_bvh):
+    """BUILD-DEFINED accumulation rule for long sample chains (configs[4]; include/minipath_hip.h MP_FLAG_CHUNKED_SUM):
+    f32 sums over 256-sample chunks + f64 total.  It must agree with the reference's single f32 chain (worker.rs:40-44) to
+    <= 1e-5 relative at sample counts where that chain is still accurate, and both must agree with an f64 sum."""
+    b = teapot_oracle_bvh
+    s = oracle.build_sampler(oracle.teapot_camera(), 256, 256)
+    tile = (120, 100, 128, 108)
+    spp = 1500  # five full chunks and a ragged one
+    chain, _ = b.render_tile(s, 256, 256, spp, 7, *tile)
+    oracle.lib().mpo_set_chunked_sum(1)
+    try:
+        chunked, _ = b.render_tile(s, 256, 256, spp, 7, *tile)
+    finally:
+        oracle.lib().mpo_set_chunked_sum(0)
+    # f64 reference sum of the same per-sample values
+    import ctypes as C
+    exact = np.zeros((8, 8, 4))
+    rgba = (C.c_float * 4)()
+    for y in range(8):
+        for x in range(8):
+            for i in range(spp):
+                oracle.lib().mpo_render_sample(b.h, C.byref(s), 256, spp, C.c_uint64(7), tile[0] + x, tile[1] + y, i, rgba, None)
+                exact[y, x] += np.array(list(rgba), np.float64)
+    exact /= spp
+    scale = np.maximum(np.abs(exact), 1e-3)
+    assert np.max(np.abs(chunked - exact) / scale) <= 1e-6  # 256-term f32 chunks + one f32 rounding of the mean; independent of spp
+    assert np.max(np.abs(chain - exact) / scale) <= 1e-5
+    assert np.max(np.abs(chain - chunked) / scale) <= 1e-5
+    assert chunked[..., 3].max() == 1.0 and np.array_equal(chunked[..., 3], chain[..., 3])  # hit counts are exact either way
+
+
+def test_materials_defaults_and_emissive_light(oracle):
+    """BUILD-DEFINED path extension with a material table: the defaults {0.75, 0} + sky 1 are the round-1
+    definition; with sky 0 only paths that reach an emissive triangle carry radiance."""
+    from tests import meshes
+
+    pos, nrm, tex, tri = meshes.make("soup_300")
+    mat = (np.arange(tri.shape[0]) % 3).astype(np.uint32)
+    plain = oracle.Bvh.build(pos, nrm, tex, tri)
+    withm = oracle.Bvh.build(pos, nrm, tex, tri, tri_material=mat)
+    assert withm.material_count == 3 and plain.material_count == 1
+    assert np.array_equal(plain.packets_bytes(), withm.packets_bytes())  # ids ride along, geometry unchanged
+    cam = oracle.Camera()
+    oracle.lib().mpo_camera_default(cam)
+    oracle.lib().mpo_camera_look_at(cam, oracle.vec3(0, 0, 9), oracle.vec3(0, 0, 0), oracle.vec3(0, 1, 0))
+    s = oracle.build_sampler(cam, 64, 64)
+    withm.set_materials([(0.75, 0.0)] * 3, 1.0)
+    a, _, sa = plain.render_tile_paths(s, 64, 64, 4, 3, 5, 16, 16, 48, 48)
+    b, _, sb = withm.render_tile_paths(s, 64, 64, 4, 3, 5, 16, 16, 48, 48)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and sa == sb
+    withm.set_materials([(0.5, 0.0), (0.0, 4.0), (0.9, 0.0)], 0.0)
+    c, _, sc = withm.render_tile_paths(s, 64, 64, 4, 3, 5, 16, 16, 48, 48)
+    assert sc == sa                       # same geometry, same RNG stream: same segments
+    assert c.max() > 0.5 and c.min() == 0.0 and not np.array_equal(a, c)
+    assert np.all(c[a[..., 3] == 0][..., 0] == 0.0)  # primary miss under a black sky carries nothing
+    try:
+        withm.set_materials([(0.5, 0.0)], 1.0)
+        raise AssertionError("table shorter than the ids in use must be refused")
+    except RuntimeError:
+        pass

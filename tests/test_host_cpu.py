@@ -40,6 +40,8 @@ def _assert_same_bvh(prod: mp.TriangleBvh, orc):
     assert np.array_equal(shading, orc.tri_shading())
     assert np.array_equal(vn.view(np.uint32), orc.vertex_normals().view(np.uint32))
     assert np.array_equal(vt.view(np.uint32), orc.vertex_tex().view(np.uint32))
+    assert np.array_equal(prod.export(with_material=True)[5], orc.tri_material())
+    assert i.material_count == orc.material_count
 
 
 def test_ctypes_mirror_matches_the_header_layout(tmp_path):
@@ -59,6 +61,8 @@ def test_ctypes_mirror_matches_the_header_layout(tmp_path):
         "mp_scene_info": (_lib.SceneInfo, None),
         "mp_hits_soa": (_lib.HitsSoA, None),
         "mp_launch_extras": (_lib.LaunchExtras, None),
+        "mp_bvh_desc": (_lib.BvhDesc, None),
+        "mp_material": (_lib.Material, None),
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "minipath_hip.h"', "int main(void) {"]
     for cname, (cls, _) in structs.items():
@@ -263,3 +267,116 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "pyoracle" not in txt and "minipath_oracle" not in txt and "liboracle" not in txt, f
+
+
+# ---- mp_scene_from_arrays: the inverse of mp_scene_export (triangle_bvh/mod.rs:20-53) ------------------------------------
+def _roundtrip(prod: mp.TriangleBvh):
+    i = prod.info()
+    inner, packets, shading, vn, vt, mat = prod.export(with_material=True)
+    again = mp.TriangleBvh.from_arrays(inner, packets, shading, vn, vt, i.root_link, list(i.bbox_min), list(i.bbox_max), tri_material=mat)
+    return i, (inner, packets, shading, vn, vt, mat), again
+
+
+@pytest.mark.parametrize("name", ["teapot", "soup_5000", "sliver_fan", "flat_plane"])
+def test_from_arrays_roundtrip_host(oracle, name):
+    """export -> from_arrays -> export is the identity, and the derived quantities (depth, triangle count, materials) are
+    recomputed from the arrays alone."""
+    prod = mp.TriangleBvh.with_obj(TEAPOT) if name == "teapot" else mp.TriangleBvh.build(*meshes.make(name))
+    i, arrays, again = _roundtrip(prod)
+    j = again.info()
+    for f in ("root_link", "inner_count", "packet_count", "vertex_count", "triangle_count", "depth", "material_count"):
+        assert getattr(i, f) == getattr(j, f), f
+    assert list(i.bbox_min) == list(j.bbox_min) and list(i.bbox_max) == list(j.bbox_max)
+    for a, b in zip(arrays, again.export(with_material=True)):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    # the oracle's own from_arrays over the product's export equals the oracle's own build (arrays + traversal)
+    orc_built = oracle.Bvh.from_obj(TEAPOT) if name == "teapot" else oracle.Bvh.build(*meshes.make(name))
+    orc_arr = oracle.Bvh.from_arrays(*arrays[:5], i.root_link, list(i.bbox_min), list(i.bbox_max), material=arrays[5])
+    assert orc_arr.depth == orc_built.depth
+    bmin, bmax = orc_built.bbox()
+    o, d = meshes.random_rays(3000, 5, bmin, bmax)
+    for x, y in zip(orc_arr.trace(o, d), orc_built.trace(o, d)):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+
+
+def test_from_arrays_rejects_malformed_trees():
+    prod = mp.TriangleBvh.with_obj(TEAPOT)
+    i, (inner, packets, shading, vn, vt, mat), _ = _roundtrip(prod)
+    args = lambda **kw: dict(dict(inner=inner, packets=packets, shading=shading, vertex_normals=vn, vertex_tex=vt, root_link=i.root_link,
+                                  bbox_min=list(i.bbox_min), bbox_max=list(i.bbox_max)), **kw)
+    links = inner.copy().view(np.uint32).reshape(-1, 32)  # 24 dwords of u16 boxes, then 8 links
+    bad = links.copy(); bad[0, 24] = (i.inner_count + 5) << 3            # inner link past the node array
+    with pytest.raises(mp.MinipathError):
+        mp.TriangleBvh.from_arrays(**args(inner=bad.view(np.uint8)))
+    bad = links.copy(); bad[0, 24] = ((i.packet_count - 1) << 3) | 7      # leaf running past the packet array
+    with pytest.raises(mp.MinipathError):
+        mp.TriangleBvh.from_arrays(**args(inner=bad.view(np.uint8)))
+    bad = links.copy(); bad[1, 24] = 0                                    # child pointing back at the root: a cycle
+    with pytest.raises(mp.MinipathError):
+        mp.TriangleBvh.from_arrays(**args(inner=bad.view(np.uint8)))
+    sh = shading.copy(); sh[3, 1] = i.vertex_count                        # vertex index out of range
+    with pytest.raises(mp.MinipathError):
+        mp.TriangleBvh.from_arrays(**args(shading=sh))
+
+
+def test_obj_usemtl_material_ids(tmp_path, oracle):
+    """`usemtl` -> TriangleShadingData.material (first-seen order from 1; 0 = before any usemtl, which is all the reference ever
+    writes, building.rs:201).  Product and oracle agree; ids travel with their triangle through the builder's reordering."""
+    rng = np.random.default_rng(4)
+    lines, nv = [], 0
+    names = [None, "red", "light", "red", "floor"]
+    expect_of_first_vertex = {}
+    for k, nm in enumerate(names):
+        if nm is not None:
+            lines.append(f"usemtl {nm}")
+        for _ in range(70):
+            c = rng.uniform(-3, 3, 3)
+            for _v in range(3):
+                p = c + rng.uniform(-0.3, 0.3, 3)
+                lines.append(f"v {p[0]:.6f} {p[1]:.6f} {p[2]:.6f}")
+            lines.append(f"f {nv + 1} {nv + 2} {nv + 3}")
+            expect_of_first_vertex[nv] = {None: 0, "red": 1, "light": 2, "floor": 3}[nm]
+            nv += 3
+    path = tmp_path / "mats.obj"
+    path.write_text("\n".join(lines) + "\n")
+    prod = mp.TriangleBvh.with_obj(str(path))
+    orc = oracle.Bvh.from_obj(str(path))
+    _assert_same_bvh(prod, orc)
+    assert prod.info().material_count == 4 and orc.material_count == 4
+    assert [prod.material_name(k) for k in range(5)] == ["", "red", "light", "floor", None]
+    shading, mat = prod.export(with_material=True)[2], prod.export(with_material=True)[5]
+    real = 0
+    for slot in range(shading.shape[0]):
+        v0 = int(shading[slot, 0])
+        if v0 == 0 and int(shading[slot, 1]) == 0:
+            continue  # padding
+        assert mat[slot] == expect_of_first_vertex[v0]
+        real += 1
+    assert real == 350 - 1 or real == 350  # the triangle whose first vertex is vertex 0 looks like padding to this loop
+
+
+def test_no_exception_crosses_the_abi(tmp_path):
+    """A caller that claims 2^31 vertices makes the host allocate 24 GB for the normals; under a 6 GB address-space limit
+    that is std::bad_alloc inside the library, which must come back as a status code (MP_ERR_NOMEM), not as an abort."""
+    import subprocess
+    import sys
+
+    code = f"""
+import resource, sys, ctypes as C
+sys.path.insert(0, {ROOT!r})
+import numpy as np
+from minipath_amd import _lib
+L = _lib.lib()
+resource.setrlimit(resource.RLIMIT_AS, (6 << 30, 6 << 30))
+pos = np.zeros((8, 3), np.float32); pos[1, 0] = pos[2, 1] = 1
+tri = np.array([[0, 1, 2]], np.uint32)
+h = C.c_void_p()
+rc = L.mp_scene_from_triangles(None, pos.ctypes.data, None, None, 1 << 31, tri.ctypes.data, 1, C.byref(h))
+print("rc", rc, L.mp_last_error().decode())
+rc2 = L.mp_scene_from_obj(None, b"/nonexistent/file.obj", C.byref(h))
+print("rc2", rc2)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rc 7 " in r.stdout and "bad_alloc" in r.stdout, r.stdout  # MP_ERR_NOMEM
+    assert "rc2 2" in r.stdout  # MP_ERR_IO

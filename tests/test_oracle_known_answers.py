@@ -323,7 +323,10 @@ def test_uniform_and_unit_disc_ranges(oracle):
         L.mpo_rng_unit_disc(C.byref(r), out)
         assert out[0] * out[0] + out[1] * out[1] <= 1.0
     # sample key
-    assert L.mpo_sample_key(0x5EED, 1920, 256, 3, 2, 5) == 0x5EED + ((2 * 1920 + 3) * 256 + 5)
+    L.mpo_seed_mix.restype = C.c_uint64
+    L.mpo_seed_mix.argtypes = [C.c_uint64]
+    assert L.mpo_seed_mix(0) == 0xE220A8397B1DCDAF  # SplitMix64 published first output for state 0
+    assert L.mpo_sample_key(0x5EED, 1920, 256, 3, 2, 5) == (L.mpo_seed_mix(0x5EED) + ((2 * 1920 + 3) * 256 + 5)) & 0xFFFFFFFFFFFFFFFF
 
 
 def test_color_to_image(oracle):
