@@ -154,11 +154,15 @@ def atrium(seed: int = 1, detail: float = 1.0):
     return m.arrays()
 
 
+ATRIUM_VIEW = ((-16.0, 4.2, 0.8), (12.0, 5.5, -0.5), 4.0)  # eye, target, f-number
+
+
 def atrium_camera():
     """Inside the hall, looking down the nave."""
     from .camera import Camera
 
-    return Camera.default().look_at((-16.0, 4.2, 0.8), (12.0, 5.5, -0.5), (0.0, 1.0, 0.0)).f_number(4.0)
+    eye, at, fnum = ATRIUM_VIEW
+    return Camera.default().look_at(eye, at, (0.0, 1.0, 0.0)).f_number(fnum)
 
 
 def write_obj(path, pos, nrm, tex, tri):

@@ -1,0 +1,224 @@
+"""GPU parity tests (-m gpu) of the round-2 features, all through the C ABI, all bit-exact against the oracle:
+mp_scene_from_arrays (import of reference-layout arrays), the material table of the build-defined path extension,
+HitRecord.material, the chunked accumulation rule (MP_FLAG_CHUNKED_SUM), seed mixing."""
+import numpy as np
+import pytest
+
+import minipath_amd as mp
+from tests import meshes
+from tests.conftest import TEAPOT
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return mp.Context(0)
+
+
+@pytest.fixture(scope="module")
+def teapot(ctx):
+    return mp.Scene(mp.TriangleBvh.with_obj(TEAPOT, ctx))
+
+
+def _render(scene, cam, st, tile=None):
+    import torch
+
+    fr = mp.FrameRenderer(scene, cam, st, tiles=None if tile is None else [mp.ScreenBlock(*tile)])
+    fr.render()
+    if tile is None:
+        img, _ = fr.untile()
+        torch.cuda.synchronize()
+        return img.cpu().numpy(), int(fr.segments.item())
+    torch.cuda.synchronize()
+    tw, th = tile[2] - tile[0], tile[3] - tile[1]
+    return fr.tile_buf[0, :th, :tw].cpu().numpy(), int(fr.segments.item())
+
+
+def _permute_inside_leaves(inner, packets, shading, mat, seed):
+    """What another sort_unstable_by_key (building.rs:295) could have produced: the real triangles of every leaf in another
+    order (padding stays at the tail); topology, boxes and quantised vertices are untouched."""
+    rng = np.random.default_rng(seed)
+    pk = packets.copy().view(np.uint16).reshape(-1, 9, 8)       # [packet][vertex*3+coord][lane]
+    sh, mt = shading.copy(), mat.copy()
+    links = inner.view(np.uint32).reshape(-1, 32)[:, 24:].reshape(-1)
+    moved = 0
+    for link in links:
+        cnt = int(link) & 7
+        if int(link) == 0xFFFFFFF8 or cnt == 0:
+            continue
+        first = int(link) >> 3
+        slots = np.arange(first * 8, (first + cnt) * 8)
+        tri = pk[first:first + cnt].transpose(0, 2, 1).reshape(-1, 9)  # [slot][9]
+        pad = np.all(tri == 0, axis=1) & np.all(sh[slots, :] == 0, axis=1)
+        n_real = int(np.max(np.nonzero(~pad)[0])) + 1 if np.any(~pad) else 0
+        perm = rng.permutation(n_real)
+        moved += int(np.sum(perm != np.arange(n_real)))
+        tri[:n_real] = tri[perm]
+        sh[slots[:n_real]] = sh[slots[:n_real]][perm]
+        mt[slots[:n_real]] = mt[slots[:n_real]][perm]
+        pk[first:first + cnt] = tri.reshape(cnt, 8, 9).transpose(0, 2, 1)
+    assert moved > 100
+    return pk.view(np.uint8).reshape(-1, 144), sh, mt
+
+
+def test_from_arrays_renders_bit_identical(ctx, teapot, oracle, teapot_oracle_bvh):
+    """mp_scene_from_arrays: export -> import -> render equals the built scene bit for bit (frame, hits); a
+    permuted-within-leaf variant -- the one documented deviation, building.rs:295 -- is rendered exactly as the oracle renders
+    the SAME arrays, and differs from the original only in triangle_index values (and in exact-t ties, if any)."""
+    import torch
+
+    built = teapot.object
+    i = built.info()
+    inner, packets, shading, vn, vt, mat = built.export(with_material=True)
+    again = mp.Scene(mp.TriangleBvh.from_arrays(inner, packets, shading, vn, vt, i.root_link, list(i.bbox_min), list(i.bbox_max), ctx, tri_material=mat))
+    assert again.object.info().stack_bound == i.stack_bound
+    cam = mp.Camera.teapot_view()
+    st = mp.RenderSettings(64, 16, (256, 256), seed=SEED)
+    a, _ = _render(teapot, cam, st)
+    b, _ = _render(again, cam, st)
+    assert np.array_equal(bits(a), bits(b))
+    st8 = mp.RenderSettings(64, 8, (256, 256), seed=SEED, max_depth=6)
+    a8, sa = _render(teapot, cam, st8)
+    b8, sb = _render(again, cam, st8)
+    assert np.array_equal(bits(a8), bits(b8)) and sa == sb
+
+    # permuted inside the leaves
+    p_packets, p_shading, p_mat = _permute_inside_leaves(inner, packets, shading, mat, 3)
+    perm = mp.Scene(mp.TriangleBvh.from_arrays(inner, p_packets, p_shading, vn, vt, i.root_link, list(i.bbox_min), list(i.bbox_max), ctx, tri_material=p_mat))
+    orc = oracle.Bvh.from_arrays(inner, p_packets, p_shading, vn, vt, i.root_link, list(i.bbox_min), list(i.bbox_max), material=p_mat)
+    bmin, bmax = teapot_oracle_bvh.bbox()
+    o, d = meshes.random_rays(20000, 9, bmin, bmax)
+    got = perm.object.intersect(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda())
+    torch.cuda.synchronize()
+    t, prim, u, v = orc.trace(o, d)
+    assert np.array_equal(got["prim"].cpu().numpy().view(np.uint32), prim)
+    for k, e in (("t", t), ("u", u), ("v", v)):
+        assert np.array_equal(bits(got[k].cpu().numpy()), bits(e)), k
+    t0, prim0, _, _ = teapot_oracle_bvh.trace(o, d)
+    assert np.array_equal(bits(t), bits(t0))                      # same closest distance whatever the lane order
+    assert 0 < int(np.sum(prim != prim0))                         # ... under other triangle_index values
+    c, _ = _render(perm, cam, st)
+    osmp = oracle.build_sampler(oracle.teapot_camera(), 256, 256)
+    of, _, _, _, _ = orc.render_image_mt(osmp, 256, 256, 16, SEED, 64, 8)
+    assert np.array_equal(bits(c), bits(of))                      # GPU == oracle on the permuted arrays
+    assert np.mean(bits(c) != bits(a)) < 1e-4                     # == the original frame except exact-t ties
+
+
+def test_materials_and_hit_record_material(ctx, oracle):
+    """material table {albedo, emission} indexed by TriangleShadingData.material, an emissive material as the
+    light under a black sky; HitRecord.material (geometry/mod.rs:78) in mp_hits_soa.  GPU == oracle bit for bit, both the
+    fused and the staged pipeline."""
+    import torch
+
+    pos, nrm, tex, tri = meshes.make("soup_5000")
+    mat = (np.arange(tri.shape[0]) % 4).astype(np.uint32)
+    scene = mp.Scene(mp.TriangleBvh.build(pos, nrm, tex, tri, ctx, tri_material=mat))
+    orc = oracle.Bvh.build(pos, nrm, tex, tri, tri_material=mat)
+    assert scene.object.info().material_count == 4
+    assert np.array_equal(scene.object.export(with_material=True)[5], orc.tri_material())
+    table = [(0.8, 0.0), (0.2, 0.0), (0.0, 6.0), (0.55, 0.25)]
+    with pytest.raises(mp.MinipathError):
+        scene.object.set_materials(table[:2])
+    import ctypes as C
+
+    oc = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(oc))
+    oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(0.5, 0.2, 11.0), oracle.vec3(0, 0, 0), oracle.vec3(0, 1, 0))
+    cam = mp.Camera.default().look_at((0.5, 0.2, 11.0), (0, 0, 0), (0, 1, 0))
+    res = (128, 96)
+    osmp = oracle.build_sampler(oc, *res)
+    for sky in (0.0, 0.5):
+        scene.object.set_materials(table, sky)
+        orc.set_materials(table, sky)
+        of, _, _, seg = orc.render_image_paths_mt(osmp, res[0], res[1], 7, 21, 5, 32, 8)
+        for wavefront in (False, True):
+            got, gseg = _render(scene, cam, mp.RenderSettings(32, 7, res, seed=21, max_depth=5, wavefront=wavefront))
+            assert np.array_equal(bits(got), bits(of)), (sky, wavefront, int(np.sum(bits(got) != bits(of))))
+            assert gseg == seg
+        assert of[..., 0].max() > 1.0  # the light is visible
+    # HitRecord.material
+    bmin, bmax = orc.bbox()
+    o, d = meshes.random_rays(5000, 2, bmin, bmax)
+    got = scene.object.intersect(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), full=True)
+    torch.cuda.synchronize()
+    gm, gp = got["material"].cpu().numpy(), got["prim"].cpu().numpy().view(np.uint32)
+    tm = orc.tri_material()
+    hit = gp != 0xFFFFFFFF
+    assert hit.sum() > 500 and np.array_equal(gm[hit].astype(np.uint32), tm[gp[hit]]) and np.all(gm[~hit] == 0)
+    r = oracle.ray_new(o[hit][0], d[hit][0])
+    assert orc.intersect(r).material == int(gm[hit][0])
+
+
+@pytest.mark.parametrize("mode", ["packets", "groups", "paths", "staged"])
+def test_chunked_sum_matches_oracle_and_any_pass_split(teapot, oracle, teapot_oracle_bvh, mode):
+    """MP_FLAG_CHUNKED_SUM (build-defined accumulation rule for long sample chains, configs[4]): f32 sums over 256-sample chunks,
+    f64 total.  GPU == oracle's statement of the same rule, bit for bit, in one launch and for ragged pass splits that cut
+    chunks in the middle; and within 1e-5 of the reference's single-chain mean."""
+    import torch
+
+    cam = mp.Camera.teapot_view()
+    res, spp, tile = (128, 128), 700, (48, 40, 80, 72)
+    depth = 4 if mode in ("paths", "staged") else 0
+    st = mp.RenderSettings(32, spp, res, seed=77, traversal="groups" if mode == "groups" else "packets", max_depth=depth,
+                           wavefront=(mode == "staged"), chunked_sum=True)
+    osmp = oracle.build_sampler(oracle.teapot_camera(), *res)
+    oracle.lib().mpo_set_chunked_sum(1)
+    try:
+        if depth:
+            of, _, _ = teapot_oracle_bvh.render_tile_paths(osmp, res[0], res[1], spp, 77, depth, *tile)
+        else:
+            of, _ = teapot_oracle_bvh.render_tile(osmp, res[0], res[1], spp, 77, *tile)
+    finally:
+        oracle.lib().mpo_set_chunked_sum(0)
+    if depth:
+        chain, _, _ = teapot_oracle_bvh.render_tile_paths(osmp, res[0], res[1], spp, 77, depth, *tile)
+    else:
+        chain, _ = teapot_oracle_bvh.render_tile(osmp, res[0], res[1], spp, 77, *tile)
+    one, _ = _render(teapot, cam, st, tile)
+    assert np.array_equal(bits(one), bits(of)), int(np.sum(bits(one) != bits(of)))
+    assert np.max(np.abs(one - chain) / np.maximum(np.abs(chain), 1e-3)) <= 1e-5
+    fr = mp.FrameRenderer(teapot, cam, st, tiles=[mp.ScreenBlock(*tile)])
+    nxt = 0
+    for count in (5, 246, 10, 300, 0):  # 5, 251, 261 (cuts chunk 1), 561 (cuts chunk 2), rest
+        nxt = fr.render_pass(nxt, count)
+    torch.cuda.synchronize()
+    assert nxt == spp
+    assert np.array_equal(bits(fr.tile_buf[0].cpu().numpy()), bits(of))
+
+
+def test_consecutive_seeds_share_no_sample_rays(ctx):
+    """with key = seed + index the frame of seed s+1 was the frame of seed s shifted by one sample.  The seed is
+    now mixed (SplitMix64) before the index is added: the rays of seeds s and s+1 have nothing in common."""
+    import ctypes as C
+
+    import torch
+
+    from minipath_amd import _lib
+
+    cam = mp.Camera.teapot_view()
+    blk = mp.ScreenBlock(10, 20, 42, 44)
+    n = blk.area()
+    rays = {}
+    for seed in (100, 101):
+        st = mp.RenderSettings(64, 16, (256, 256), seed=seed)
+        s, ss = cam.build_sampler(st.resolution).as_struct(), st.as_struct()
+        per_sample = []
+        for sample in range(3):
+            bufs = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(6)]
+            _lib.check(_lib.lib().mp_generate_rays(ctx.handle, C.byref(s), C.byref(ss), blk.as_struct(), sample, *[b.data_ptr() for b in bufs], None))
+            torch.cuda.synchronize()
+            per_sample.append(np.stack([b.cpu().numpy() for b in bufs[3:]], -1))
+        rays[seed] = np.stack(per_sample)  # [sample][pixel][dir xyz]
+    a = {tuple(r) for r in bits(rays[100]).reshape(-1, 3).tolist()}
+    b = {tuple(r) for r in bits(rays[101]).reshape(-1, 3).tolist()}
+    assert len(a) == 3 * n and len(a & b) == 0
