@@ -13,8 +13,10 @@
  *     failure on the calling thread is mp_last_error();
  *   - "d_" pointers are device (HBM) pointers on the context's GPU, everything else is host memory;
  *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
- *   - one context drives ONE GPU.  Multi-GPU is one process (and one context) per GPU, tiles sharded across
- *     ranks by the caller, framebuffer gathered with RCCL by the caller (bench.py / minipath_amd.distributed).
+ *   - one context drives ONE GPU.  Multi-GPU, two ways: (a) one process and one context PER GPU, tiles sharded across
+ *     ranks by the caller, framebuffer gathered with RCCL by the caller (bench.py / minipath_amd.distributed);
+ *     (b) ONE process driving several contexts behind this ABI: mp_render_begin_multi (render()'s worker pool over
+ *     devices) and mp_render_frame_multi (device-resident frame, shards gathered by peer copies over xGMI).
  *
  * Seeded mode.  The reference seeds every worker's RNG from the OS (worker.rs:25), so it has no reproducible
  * sample stream.  This library defines one: sample s of pixel (x,y) uses
@@ -275,6 +277,15 @@ int mp_render_tiles_device_ex(mp_ctx *ctx, const mp_scene *scene, const mp_camer
  * f32 frame and/or its color_to_image u8 frame (either may be NULL). */
 int mp_untile(mp_ctx *ctx, const mp_settings *settings, const mp_block *tiles, size_t n_tiles,
               const float *d_tiles_f32, float *d_image_f32, uint8_t *d_image_u8, void *stream);
+/* One whole frame over n GPUs of this process, device-resident (SURVEY 8e in one process): rank r renders tiles r, r+n, ... of
+ * the row-major tile grid in ONE launch on ctxs[r]'s own stream into its shard; the shards are copied to ctxs[0]'s device by
+ * peer copies (hipMemcpyPeerAsync: every peer over its own xGMI link) on `stream` (a stream of ctxs[0]'s device) and scattered
+ * there into d_image_f32 / d_image_u8 (image-major, either may be NULL).  Asynchronous: the frame is complete when `stream` is.
+ * All samples of a pixel stay on one device, so the image does not depend on n.  *ray_segments (host, optional) receives the
+ * Object::intersect calls of the frame for the reference semantics.  Contexts must be distinct; two may share a device. */
+int mp_render_frame_multi(mp_ctx *const *ctxs, const mp_scene *const *scenes, int n, const mp_camera_sampler *sampler,
+                          const mp_settings *settings, float *d_image_f32, uint8_t *d_image_u8, uint64_t *ray_segments,
+                          void *stream);
 /* Rays traced (Object::intersect calls) and their wall time inside the last mp_render_tiles_device launch is
  * NOT measured here: the caller brackets the stream with events. */
 
@@ -284,6 +295,14 @@ int mp_untile(mp_ctx *ctx, const mp_settings *settings, const mp_block *tiles, s
  * start and once per tile end. */
 int mp_render_begin(mp_ctx *ctx, const mp_scene *scene, const mp_camera *camera, const mp_settings *settings,
                     mp_tile_started_cb started, mp_tile_finished_cb finished, void *user, mp_render **out);
+/* render() over n GPUs of this process (machinery.rs:51-116 with devices in place of cores): one library-owned host thread
+ * per (ctxs[i], scenes[i]) pair pulls batches of tiles from ONE shared atomic queue (get_next_tile, :205-208), renders them on
+ * its device and files them into the one host image under its lock; callbacks come from all n threads (concurrently, like the
+ * reference's worker threads).  scenes[i] is the same scene uploaded to ctxs[i].  mp_render_begin == n = 1.  Several contexts
+ * may share a device (this is how the path is tested on a one-GPU box). */
+int mp_render_begin_multi(mp_ctx *const *ctxs, const mp_scene *const *scenes, int n, const mp_camera *camera,
+                          const mp_settings *settings, mp_tile_started_cb started, mp_tile_finished_cb finished, void *user,
+                          mp_render **out);
 int mp_render_progress(const mp_render *r, mp_progress *out);        /* RenderProgress::progress :133-142 */
 int mp_render_is_finished(const mp_render *r, int *finished);        /* ::is_finished :144-146 */
 int mp_render_elapsed_ns(const mp_render *r, uint64_t *ns);          /* ::elapsed :150-157 */

@@ -8,10 +8,11 @@ from ._lib import MinipathError, MP_NO_PRIM, MP_LINK_NULL, SO_PATH  # noqa: F401
 from .camera import Camera, CameraSampler  # noqa: F401
 from .screen_block import ScreenBlock, tile_ordering  # noqa: F401
 from .scene import Context, Scene, Sphere, TriangleBvh  # noqa: F401
-from .renderer import RenderProgress, RenderProgressSnapshot, RenderSettings, render, render_tile, FrameRenderer  # noqa: F401
+from .renderer import (RenderProgress, RenderProgressSnapshot, RenderSettings, render, render_multi, render_tile,  # noqa: F401
+                       FrameRenderer, MultiDeviceFrame)
 
 __all__ = [
-    "Camera", "CameraSampler", "Context", "FrameRenderer", "MinipathError", "RenderProgress",
+    "Camera", "CameraSampler", "Context", "FrameRenderer", "MinipathError", "MultiDeviceFrame", "RenderProgress", "render_multi",
     "RenderProgressSnapshot", "RenderSettings", "Scene", "ScreenBlock", "Sphere", "TriangleBvh", "render", "render_tile",
     "tile_ordering",
 ]

@@ -207,6 +207,16 @@ SIGNATURES = {
         [C.c_void_p, C.c_void_p, C.POINTER(CameraStruct), C.POINTER(SettingsStruct), STARTED_CB, FINISHED_CB, C.c_void_p,
          C.POINTER(C.c_void_p)],
     ),
+    "mp_render_begin_multi": (
+        C.c_int,
+        [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(CameraStruct), C.POINTER(SettingsStruct), STARTED_CB,
+         FINISHED_CB, C.c_void_p, C.POINTER(C.c_void_p)],
+    ),
+    "mp_render_frame_multi": (
+        C.c_int,
+        [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(SamplerStruct), C.POINTER(SettingsStruct), C.c_void_p,
+         C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p],
+    ),
     "mp_render_progress": (C.c_int, [C.c_void_p, C.POINTER(Progress)]),
     "mp_render_is_finished": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "mp_render_elapsed_ns": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

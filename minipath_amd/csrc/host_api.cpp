@@ -87,7 +87,20 @@ struct mp_ctx {
         std::vector<uint32_t> order;
         unsigned char* d_buf = nullptr;  // tiles, then order
         uint64_t last_use = 0;
+        int device = 0;
+        TileList() = default;
+        TileList(const TileList&) = delete;
+        TileList& operator=(const TileList&) = delete;
+        ~TileList() {  // runs when the cache AND every caller that still holds the list have let go; hipFree waits for the device
+            if (!d_buf) return;
+            int prev = -1;
+            (void)hipGetDevice(&prev);
+            if (prev != device) (void)hipSetDevice(device);
+            (void)hipFree(d_buf);
+            if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+        }
     };
+    using TileListRef = std::shared_ptr<TileList>;
     // Buffers of the render() worker (stream, device tile-major f32/u8 + tile list, pinned host mirrors), kept between calls:
     // creating and freeing them costs several milliseconds per render() otherwise.
     struct WorkerSlot {
@@ -106,12 +119,28 @@ struct mp_ctx {
     int acquire_slot(size_t tiles, size_t per_tile, WorkerSlot& out);
     void release_slot(const WorkerSlot& s);
     static void destroy_slot(WorkerSlot& s);
+    // Buffers of mp_render_frame_multi: this device's shard (tile-major), its stream and completion event; on the gathering
+    // device also the rank-major gather buffer and the event after which the shards may be overwritten by the next frame.
+    struct MultiBuf {
+        float* d_shard = nullptr;
+        size_t shard_cap = 0;  // floats
+        hipStream_t stream = nullptr;
+        hipEvent_t rendered = nullptr;
+        float* d_gather = nullptr;
+        size_t gather_cap = 0;
+        hipEvent_t gathered = nullptr;
+        bool gathered_valid = false;
+    } multi;
+    std::mutex multi_mu;
     static constexpr size_t kTileLists = 32;
     std::mutex tile_mutex;
-    std::vector<TileList> tile_lists;
+    std::vector<TileListRef> tile_lists;
     uint64_t tile_clock = 0;
-    // Returns device pointers valid until the entry is evicted; eviction frees with hipFree, which waits for the device.
-    int device_tiles(const mp_block* tiles, size_t n, const uint32_t* order, const mp_block** d_tiles, const uint32_t** d_order);
+    // Returns device pointers and `keep`, a reference on the cache entry: the caller holds it until its launch is enqueued, so a
+    // concurrent caller that evicts the entry (LRU, 32 lists) cannot free the buffer in between; the buffer is freed when the
+    // last reference goes (hipFree then waits for the kernels already enqueued).
+    int device_tiles(const mp_block* tiles, size_t n, const uint32_t* order, TileListRef& keep, const mp_block** d_tiles,
+                     const uint32_t** d_order);
 };
 
 struct mp_scene {
@@ -147,40 +176,43 @@ struct DeviceGuard {
 
 }  // namespace
 
-int mp_ctx::device_tiles(const mp_block* tiles, size_t n, const uint32_t* order, const mp_block** d_tiles, const uint32_t** d_order) {
-    std::lock_guard<std::mutex> lock(tile_mutex);
-    const size_t tb = n * sizeof(mp_block), ob = order ? n * sizeof(uint32_t) : 0;
-    TileList* hit = nullptr;
-    for (TileList& e : tile_lists)
-        if (e.tiles.size() == n && e.order.size() == (order ? n : 0) && std::memcmp(e.tiles.data(), tiles, tb) == 0 &&
-            (!order || std::memcmp(e.order.data(), order, ob) == 0)) {
-            hit = &e;
-            break;
+int mp_ctx::device_tiles(const mp_block* tiles, size_t n, const uint32_t* order, TileListRef& keep, const mp_block** d_tiles,
+                         const uint32_t** d_order) {
+    TileListRef evicted;  // released after the lock is dropped: its hipFree may wait for the device
+    {
+        std::lock_guard<std::mutex> lock(tile_mutex);
+        const size_t tb = n * sizeof(mp_block), ob = order ? n * sizeof(uint32_t) : 0;
+        TileListRef hit;
+        for (TileListRef& e : tile_lists)
+            if (e->tiles.size() == n && e->order.size() == (order ? n : 0) && std::memcmp(e->tiles.data(), tiles, tb) == 0 &&
+                (!order || std::memcmp(e->order.data(), order, ob) == 0)) {
+                hit = e;
+                break;
+            }
+        if (!hit) {
+            if (tile_lists.size() >= kTileLists) {  // evict the least recently used list
+                size_t lru = 0;
+                for (size_t i = 1; i < tile_lists.size(); i++)
+                    if (tile_lists[i]->last_use < tile_lists[lru]->last_use) lru = i;
+                evicted = std::move(tile_lists[lru]);
+                tile_lists.erase(tile_lists.begin() + static_cast<std::ptrdiff_t>(lru));
+            }
+            auto e = std::make_shared<TileList>();
+            e->device = device;
+            e->tiles.assign(tiles, tiles + n);
+            if (order) e->order.assign(order, order + n);
+            MP_HIP(hipMalloc(reinterpret_cast<void**>(&e->d_buf), tb + ob));
+            hipError_t err = hipMemcpy(e->d_buf, tiles, tb, hipMemcpyHostToDevice);
+            if (err == hipSuccess && order) err = hipMemcpy(e->d_buf + tb, order, ob, hipMemcpyHostToDevice);
+            if (err != hipSuccess) return hip_fail(err, "hipMemcpy(tile list)");
+            tile_lists.push_back(e);
+            hit = e;
         }
-    if (!hit) {
-        if (tile_lists.size() >= kTileLists) {  // evict the least recently used list
-            size_t lru = 0;
-            for (size_t i = 1; i < tile_lists.size(); i++)
-                if (tile_lists[i].last_use < tile_lists[lru].last_use) lru = i;
-            (void)hipFree(tile_lists[lru].d_buf);
-            tile_lists.erase(tile_lists.begin() + static_cast<std::ptrdiff_t>(lru));
-        }
-        TileList e;
-        e.tiles.assign(tiles, tiles + n);
-        if (order) e.order.assign(order, order + n);
-        MP_HIP(hipMalloc(reinterpret_cast<void**>(&e.d_buf), tb + ob));
-        hipError_t err = hipMemcpy(e.d_buf, tiles, tb, hipMemcpyHostToDevice);
-        if (err == hipSuccess && order) err = hipMemcpy(e.d_buf + tb, order, ob, hipMemcpyHostToDevice);
-        if (err != hipSuccess) {
-            (void)hipFree(e.d_buf);
-            return hip_fail(err, "hipMemcpy(tile list)");
-        }
-        tile_lists.push_back(std::move(e));
-        hit = &tile_lists.back();
+        hit->last_use = ++tile_clock;
+        *d_tiles = reinterpret_cast<const mp_block*>(hit->d_buf);
+        if (d_order) *d_order = order ? reinterpret_cast<const uint32_t*>(hit->d_buf + tb) : nullptr;
+        keep = std::move(hit);
     }
-    hit->last_use = ++tile_clock;
-    *d_tiles = reinterpret_cast<const mp_block*>(hit->d_buf);
-    if (d_order) *d_order = order ? reinterpret_cast<const uint32_t*>(hit->d_buf + tb) : nullptr;
     return MP_OK;
 }
 
@@ -492,8 +524,14 @@ void mp_ctx_destroy(mp_ctx* ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-    for (auto& e : ctx->tile_lists) (void)hipFree(e.d_buf);
+    ctx->tile_lists.clear();
     for (auto& sl : ctx->free_slots) mp_ctx::destroy_slot(sl);
+    if (ctx->multi.stream) (void)hipStreamSynchronize(ctx->multi.stream);
+    if (ctx->multi.d_shard) (void)hipFree(ctx->multi.d_shard);
+    if (ctx->multi.d_gather) (void)hipFree(ctx->multi.d_gather);
+    if (ctx->multi.rendered) (void)hipEventDestroy(ctx->multi.rendered);
+    if (ctx->multi.gathered) (void)hipEventDestroy(ctx->multi.gathered);
+    if (ctx->multi.stream) (void)hipStreamDestroy(ctx->multi.stream);
     delete ctx;
 }
 
@@ -792,7 +830,8 @@ int mp_render_tiles_device_ex(mp_ctx* ctx, const mp_scene* scene, const mp_camer
     DeviceGuard g(ctx->device);
     const mp_block* d_tiles = nullptr;
     const uint32_t* d_order = nullptr;
-    int rc = ctx->device_tiles(tiles, n_tiles, tile_order, &d_tiles, &d_order);
+    mp_ctx::TileListRef keep;  // held until the launch below is enqueued
+    int rc = ctx->device_tiles(tiles, n_tiles, tile_order, keep, &d_tiles, &d_order);
     if (rc) return rc;
     if (!rc && d_ray_segments) {
         uint64_t init = 0;
@@ -817,13 +856,103 @@ int mp_untile(mp_ctx* ctx, const mp_settings* settings, const mp_block* tiles, s
     if (n_tiles > 0xFFFFFFFFull) return fail(MP_ERR_INVALID, "too many tiles");
     DeviceGuard g(ctx->device);
     const mp_block* d_tiles = nullptr;
-    int rc = ctx->device_tiles(tiles, n_tiles, nullptr, &d_tiles, nullptr);  // cached: no per-frame upload
+    mp_ctx::TileListRef keep;
+    int rc = ctx->device_tiles(tiles, n_tiles, nullptr, keep, &d_tiles, nullptr);  // cached: no per-frame upload
     if (rc) return rc;
     std::string err;
     rc = launch_untile(settings->width, settings->height, settings->tile_size, d_tiles, static_cast<uint32_t>(n_tiles), d_tiles_f32,
                        d_image_f32, d_image_u8, stream, err);
     if (rc) fail(rc, err);
     return rc;
+    });
+}
+
+int mp_render_frame_multi(mp_ctx* const* ctxs, const mp_scene* const* scenes, int n, const mp_camera_sampler* sampler,
+                          const mp_settings* settings, float* d_image_f32, uint8_t* d_image_u8, uint64_t* ray_segments,
+                          void* stream) {
+    return guarded([&]() -> int {
+    if (!ctxs || !scenes || n < 1 || n > 64 || !sampler || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
+    if (settings->flags & (MP_FLAG_ACCUMULATE | MP_FLAG_WAVEFRONT)) return fail(MP_ERR_INVALID, "mp_render_frame_multi renders whole frames with the fused kernels");
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i] || !scenes[i] || scenes[i]->ctx != ctxs[i]) return fail(MP_ERR_INVALID, "scenes[i] must live on ctxs[i]");
+        for (int j = 0; j < i; j++)
+            if (ctxs[j] == ctxs[i]) return fail(MP_ERR_INVALID, "every rank needs its own context (two contexts may share a device)");
+    }
+    const uint32_t ts = settings->tile_size;
+    const std::vector<mp_block> all = tile_ordering(mp_block{0, 0, settings->width, settings->height}, ts, 0);
+    const size_t per_rank = (all.size() + static_cast<size_t>(n) - 1) / static_cast<size_t>(n);
+    const size_t tile_floats = static_cast<size_t>(ts) * ts * 4;
+    hipStream_t st0 = static_cast<hipStream_t>(stream);
+    mp_ctx* c0 = ctxs[0];
+    // gather buffer on device 0, rank-major: slot r*per_rank + k = k-th tile of rank r (tiles r, r+n, r+2n, ... of the grid)
+    std::vector<mp_block> order(per_rank * static_cast<size_t>(n), mp_block{0, 0, 0, 0});
+    std::vector<std::vector<mp_block>> shard(static_cast<size_t>(n));
+    for (size_t t = 0; t < all.size(); t++) {
+        const size_t r = t % static_cast<size_t>(n), k = t / static_cast<size_t>(n);
+        order[r * per_rank + k] = all[t];
+        shard[r].push_back(all[t]);
+    }
+    {
+        DeviceGuard g(c0->device);
+        std::lock_guard<std::mutex> lk(c0->multi_mu);
+        if (c0->multi.gather_cap < order.size() * tile_floats) {
+            if (c0->multi.d_gather) (void)hipFree(c0->multi.d_gather);
+            c0->multi.d_gather = nullptr;
+            MP_HIP(hipMalloc(reinterpret_cast<void**>(&c0->multi.d_gather), order.size() * tile_floats * 4));
+            c0->multi.gather_cap = order.size() * tile_floats;
+        }
+        if (!c0->multi.gathered) MP_HIP(hipEventCreateWithFlags(&c0->multi.gathered, hipEventDisableTiming));
+    }
+    uint64_t segs = 0;
+    // every rank renders its shard in one launch on its own stream (machinery.rs:51-116: the workers own their tiles)
+    for (int r = 0; r < n; r++) {
+        mp_ctx* c = ctxs[r];
+        if (shard[static_cast<size_t>(r)].empty()) continue;
+        DeviceGuard g(c->device);
+        std::lock_guard<std::mutex> lk(c->multi_mu);
+        if (!c->multi.stream) MP_HIP(hipStreamCreateWithFlags(&c->multi.stream, hipStreamNonBlocking));
+        if (!c->multi.rendered) MP_HIP(hipEventCreateWithFlags(&c->multi.rendered, hipEventDisableTiming));
+        if (c->multi.shard_cap < per_rank * tile_floats) {
+            (void)hipStreamSynchronize(c->multi.stream);
+            if (c->multi.d_shard) (void)hipFree(c->multi.d_shard);
+            c->multi.d_shard = nullptr;
+            MP_HIP(hipMalloc(reinterpret_cast<void**>(&c->multi.d_shard), per_rank * tile_floats * 4));
+            c->multi.shard_cap = per_rank * tile_floats;
+        }
+        // the previous frame's gather must have read this shard before it is overwritten
+        if (c0->multi.gathered_valid) MP_HIP(hipStreamWaitEvent(c->multi.stream, c0->multi.gathered, 0));
+        const mp_block* d_tiles = nullptr;
+        mp_ctx::TileListRef keep;
+        int rc = c->device_tiles(shard[static_cast<size_t>(r)].data(), shard[static_cast<size_t>(r)].size(), nullptr, keep, &d_tiles, nullptr);
+        if (rc) return rc;
+        rc = render_tiles_device(c, scenes[r], *sampler, *settings, d_tiles, shard[static_cast<size_t>(r)].size(), c->multi.d_shard, c->multi.stream);
+        if (rc) return rc;
+        MP_HIP(hipEventRecord(c->multi.rendered, c->multi.stream));
+        if (!(settings->flags & MP_FLAG_PATHS))
+            for (const mp_block& b : shard[static_cast<size_t>(r)]) segs += static_cast<uint64_t>(b.max_x - b.min_x) * (b.max_y - b.min_y) * settings->sample_count;
+    }
+    if (ray_segments) *ray_segments = segs;  // reference semantics only (0 with MP_FLAG_PATHS: use mp_render_tiles_device_counted)
+    // gather: every peer's shard travels over its own link to device 0, then one un-tile kernel there
+    DeviceGuard g0(c0->device);
+    for (int r = 0; r < n; r++) {
+        mp_ctx* c = ctxs[r];
+        const size_t nt = shard[static_cast<size_t>(r)].size();
+        if (nt == 0) continue;
+        MP_HIP(hipStreamWaitEvent(st0, c->multi.rendered, 0));
+        MP_HIP(hipMemcpyPeerAsync(c0->multi.d_gather + static_cast<size_t>(r) * per_rank * tile_floats, c0->device, c->multi.d_shard, c->device,
+                                  nt * tile_floats * 4, st0));
+    }
+    MP_HIP(hipEventRecord(c0->multi.gathered, st0));
+    c0->multi.gathered_valid = true;
+    const mp_block* d_order = nullptr;
+    mp_ctx::TileListRef keep0;
+    int rc = c0->device_tiles(order.data(), order.size(), nullptr, keep0, &d_order, nullptr);
+    if (rc) return rc;
+    std::string err;
+    rc = launch_untile(settings->width, settings->height, ts, d_order, static_cast<uint32_t>(order.size()), c0->multi.d_gather, d_image_f32,
+                       d_image_u8, st0, err);
+    if (rc) return fail(rc, err);
+    return MP_OK;
     });
 }
 
@@ -862,8 +991,9 @@ int mp_render_tile(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* 
 
 // ---- render() / RenderProgress (machinery.rs) -------------------------------------------------------------------
 struct mp_render {
-    mp_ctx* ctx = nullptr;
-    const mp_scene* scene = nullptr;
+    // one worker thread per device (machinery.rs:51-116: one worker per core); worker i renders on ctxs[i] / scenes[i]
+    std::vector<mp_ctx*> ctxs;
+    std::vector<const mp_scene*> scenes;
     mp_camera_sampler sampler{};
     mp_settings settings{};
     mp_tile_started_cb started = nullptr;
@@ -880,15 +1010,19 @@ struct mp_render {
     std::mutex end_mu;
     bool ended = false;
     std::chrono::nanoseconds elapsed{0};
-    std::thread worker;
-    int status = MP_OK;
+    std::vector<std::thread> workers;
+    std::atomic<int> live_workers{0};
+    std::mutex status_mu;
+    int status = MP_OK;                          // first error of any worker
     std::string error;
+    size_t batch = 1;                            // tiles per get_next_tile() grab
 };
 
 namespace {
 
-void render_worker(mp_render* r) {
-    mp_ctx* ctx = r->ctx;
+void render_worker(mp_render* r, size_t wi) {
+    mp_ctx* ctx = r->ctxs[wi];
+    const mp_scene* scene = r->scenes[wi];
     const mp_settings& st = r->settings;
     const uint32_t ts = st.tile_size;
     const size_t per_tile = static_cast<size_t>(ts) * ts * 4;  // floats (and u8 bytes) per tile slot
@@ -896,18 +1030,23 @@ void render_worker(mp_render* r) {
     // callbacks keep flowing (the reference hands out one tile per worker thread).  Two batches are in flight: while the GPU
     // renders and quantises (color_to_image) batch k+1 and copies it to pinned host memory, this thread files batch k's rows
     // into the image and runs its callbacks.
-    const size_t units_per_tile = static_cast<size_t>((ts + 7) / 8) * ((ts + 7) / 8);
-    const size_t batch = std::max<size_t>(1, (static_cast<size_t>(ctx->cu_count) * 16 + units_per_tile - 1) / units_per_tile);
+    const size_t batch = r->batch;
+    int my_status = MP_OK;  // this worker's view; the shared status records the first error of any worker
     auto set_error = [&](int code, const std::string& msg) {
-        r->status = code;
-        r->error = msg;
+        my_status = code;
+        std::lock_guard<std::mutex> lk(r->status_mu);
+        if (r->status == MP_OK) {
+            r->status = code;
+            r->error = msg;
+        }
+        r->next_tile.store(r->tiles.size(), std::memory_order_release);  // no new tiles for the other workers either
     };
     using Slot = mp_ctx::WorkerSlot;
     Slot slot[2];
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) set_error(MP_ERR_HIP, std::string("render worker setup: ") + hipGetErrorString(e));
     for (Slot& s : slot)
-        if (r->status == MP_OK) {
+        if (my_status == MP_OK) {
             int rc = ctx->acquire_slot(batch, per_tile, s);
             if (rc) set_error(rc, mp_last_error());
         }
@@ -936,13 +1075,13 @@ void render_worker(mp_render* r) {
         }
     };
     int cur = 0;
-    while (r->status == MP_OK) {
+    while (my_status == MP_OK) {
         // get_next_tile (machinery.rs:205-208): abort() stores `len` so no new tiles are handed out
         size_t first = r->next_tile.fetch_add(batch, std::memory_order_acq_rel);
         if (first >= total) break;
         Slot& s = slot[cur];
         retire(s);  // the batch issued two rounds ago
-        if (r->status != MP_OK) break;
+        if (my_status != MP_OK) break;
         s.first = first;
         s.n = std::min(batch, total - first);
         const mp_block* t = &r->tiles[first];
@@ -950,7 +1089,7 @@ void render_worker(mp_render* r) {
             for (size_t i = 0; i < s.n; i++) r->started(r->user, t[i]);  // machinery.rs:75
         e = hipMemcpyAsync(s.d_tiles, t, s.n * sizeof(mp_block), hipMemcpyHostToDevice, s.stream);
         if (e != hipSuccess) { set_error(MP_ERR_HIP, std::string("hipMemcpyAsync(tiles): ") + hipGetErrorString(e)); break; }
-        int rc = render_tiles_device(ctx, r->scene, r->sampler, st, s.d_tiles, s.n, s.d_f32, s.stream);
+        int rc = render_tiles_device(ctx, scene, r->sampler, st, s.d_tiles, s.n, s.d_f32, s.stream);
         std::string err;
         if (!rc) {
             rc = launch_quantise(s.d_f32, s.d_u8, static_cast<uint64_t>(s.n) * ts * ts, s.stream, err);
@@ -971,12 +1110,14 @@ void render_worker(mp_render* r) {
         s.busy = false;
         ctx->release_slot(s);
     }
-    {
-        std::lock_guard<std::mutex> lk(r->end_mu);  // machinery.rs:107-113
-        r->elapsed = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - r->start);
-        r->ended = true;
+    if (r->live_workers.fetch_sub(1, std::memory_order_acq_rel) == 1) {  // the last worker out closes the render
+        {
+            std::lock_guard<std::mutex> lk(r->end_mu);  // machinery.rs:107-113
+            r->elapsed = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - r->start);
+            r->ended = true;
+        }
+        r->finished_flag.store(true, std::memory_order_release);
     }
-    r->finished_flag.store(true, std::memory_order_release);
 }
 
 }  // namespace
@@ -985,13 +1126,22 @@ extern "C" {
 
 int mp_render_begin(mp_ctx* ctx, const mp_scene* scene, const mp_camera* camera, const mp_settings* settings,
                     mp_tile_started_cb started, mp_tile_finished_cb finished, void* user, mp_render** out) {
+    return mp_render_begin_multi(&ctx, &scene, 1, camera, settings, started, finished, user, out);
+}
+
+int mp_render_begin_multi(mp_ctx* const* ctxs, const mp_scene* const* scenes, int n, const mp_camera* camera,
+                          const mp_settings* settings, mp_tile_started_cb started, mp_tile_finished_cb finished, void* user,
+                          mp_render** out) {
     return guarded([&]() -> int {
-    if (!ctx || !scene || !camera || !out || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
+    if (!ctxs || !scenes || n < 1 || n > 64 || !camera || !out || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
     if (settings->flags & MP_FLAG_ACCUMULATE) return fail(MP_ERR_INVALID, "render() draws every sample of a tile at once (worker.rs:32-49): MP_FLAG_ACCUMULATE is for mp_render_tiles_device");
-    if (scene->ctx != ctx) return fail(MP_ERR_INVALID, "scene belongs to another context");
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i] || !scenes[i]) return fail(MP_ERR_INVALID, "NULL context / scene");
+        if (scenes[i]->ctx != ctxs[i]) return fail(MP_ERR_INVALID, "scenes[i] must live on ctxs[i] (the scene is replicated per device)");
+    }
     auto r = std::make_unique<mp_render>();
-    r->ctx = ctx;
-    r->scene = scene;
+    r->ctxs.assign(ctxs, ctxs + n);
+    r->scenes.assign(scenes, scenes + n);
     r->settings = *settings;
     camera_build_sampler(*camera, settings->width, settings->height, r->sampler);  // machinery.rs:65
     r->started = started;
@@ -1003,10 +1153,20 @@ int mp_render_begin(mp_ctx* ctx, const mp_scene* scene, const mp_camera* camera,
     r->tiles = tile_ordering(mp_block{0, 0, settings->width, settings->height}, settings->tile_size, shuffle);
     r->image_u8.assign(static_cast<size_t>(settings->width) * settings->height * 4, 0);   // RgbaImage::new :34
     r->image_f32.assign(static_cast<size_t>(settings->width) * settings->height * 4, 0.0f);
+    // A batch is what one launch renders: enough work units to fill every CU a few times over, small enough that the tile
+    // callbacks keep flowing and that several devices share the queue evenly (the reference hands out one tile per worker).
+    const uint32_t ts = settings->tile_size;
+    const size_t units_per_tile = static_cast<size_t>((ts + 7) / 8) * ((ts + 7) / 8);
+    size_t batch = std::max<size_t>(1, (static_cast<size_t>(ctxs[0]->cu_count) * 16 + units_per_tile - 1) / units_per_tile);
+    if (n > 1) batch = std::max<size_t>(1, std::min(batch, r->tiles.size() / (static_cast<size_t>(n) * 4)));
+    r->batch = batch;
     r->start = std::chrono::steady_clock::now();
+    r->live_workers.store(n);
     try {
-        r->worker = std::thread(render_worker, r.get());
+        for (int i = 0; i < n; i++) r->workers.emplace_back(render_worker, r.get(), static_cast<size_t>(i));
     } catch (const std::exception& ex) {
+        r->next_tile.store(r->tiles.size(), std::memory_order_release);  // the workers already running find no tiles
+        for (auto& t : r->workers) t.join();
         return fail(MP_ERR_UNSUPPORTED, std::string("thread spawn failed: ") + ex.what());  // machinery.rs:116
     }
     *out = r.release();
@@ -1054,7 +1214,8 @@ int mp_render_abort(mp_render* r) {
 int mp_render_wait(mp_render* r) {
     return guarded([&]() -> int {
     if (!r) return fail(MP_ERR_INVALID, "NULL argument");
-    if (r->worker.joinable()) r->worker.join();
+    for (auto& t : r->workers)
+        if (t.joinable()) t.join();
     if (r->status != MP_OK) return fail(r->status, r->error);
     return MP_OK;
     });
@@ -1080,10 +1241,9 @@ int mp_render_image_f32(mp_render* r, float* dst) {
 
 void mp_render_destroy(mp_render* r) {
     if (!r) return;
-    if (r->worker.joinable()) {
-        r->next_tile.store(r->tiles.size(), std::memory_order_release);
-        r->worker.join();
-    }
+    r->next_tile.store(r->tiles.size(), std::memory_order_release);
+    for (auto& t : r->workers)
+        if (t.joinable()) t.join();
     delete r;
 }
 

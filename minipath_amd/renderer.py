@@ -143,6 +143,77 @@ def render(
     return RenderProgress(h, settings, (cb1, cb2, scene))
 
 
+def render_multi(
+    scenes: Sequence[Scene],
+    camera: Camera,
+    settings: RenderSettings,
+    started_tile_callback: Optional[Callable[[ScreenBlock], None]] = None,
+    finished_tile_callback: Optional[Callable[[ScreenBlock, RenderProgressSnapshot], None]] = None,
+) -> RenderProgress:
+    """render() over several GPUs of this process (mp_render_begin_multi): scenes[i] is the same scene uploaded to its own
+    Context; one library-owned worker thread per scene pulls tiles from the one shared queue (machinery.rs:51-116 with devices
+    in place of cores).  Callbacks may run concurrently on several threads."""
+    if not scenes:
+        raise ValueError("no scenes")
+    for sc in scenes:
+        if sc.object.ctx is None:
+            raise _lib.MinipathError(1, "scene is host-only: build it with a Context")
+
+    def _started(_user, blk):
+        if started_tile_callback:
+            started_tile_callback(ScreenBlock(*blk.as_tuple()))
+
+    def _finished(_user, blk, prog):
+        if finished_tile_callback:
+            finished_tile_callback(ScreenBlock(*blk.as_tuple()), RenderProgressSnapshot(prog.finished, prog.total))
+
+    cb1 = _lib.STARTED_CB(_started) if started_tile_callback else _lib.STARTED_CB()
+    cb2 = _lib.FINISHED_CB(_finished) if finished_tile_callback else _lib.FINISHED_CB()
+    n = len(scenes)
+    ctxs = (C.c_void_p * n)(*[sc.object.ctx.handle for sc in scenes])
+    hs = (C.c_void_p * n)(*[sc.object.handle for sc in scenes])
+    h = C.c_void_p()
+    cam = camera._struct()
+    st = settings.as_struct()
+    _lib.check(_lib.lib().mp_render_begin_multi(ctxs, hs, n, C.byref(cam), C.byref(st), cb1, cb2, None, C.byref(h)))
+    return RenderProgress(h, settings, (cb1, cb2, list(scenes)))
+
+
+class MultiDeviceFrame:
+    """One process, several GPUs, device-resident frame (mp_render_frame_multi): rank r = scenes[r] renders tiles r::n in one
+    launch on its own device, shards travel to scenes[0]'s device by peer copies, un-tile there.  The single-process
+    counterpart of minipath_amd.distributed.DistributedFrame (one process per GPU + RCCL)."""
+
+    def __init__(self, scenes: Sequence[Scene], camera: Camera, settings: RenderSettings):
+        import torch
+
+        self.scenes, self.settings = list(scenes), settings
+        n = len(self.scenes)
+        self._ctxs = (C.c_void_p * n)(*[sc.object.ctx.handle for sc in self.scenes])
+        self._hs = (C.c_void_p * n)(*[sc.object.handle for sc in self.scenes])
+        self._sampler = camera.build_sampler(settings.resolution).as_struct()
+        self._st = settings.as_struct()
+        self.device = torch.device("cuda", self.scenes[0].object.ctx.device_id)
+        w, h = settings.resolution
+        self.image = torch.zeros((h, w, 4), dtype=torch.float32, device=self.device)
+        self.image_u8 = torch.zeros((h, w, 4), dtype=torch.uint8, device=self.device)
+        self.segments = 0
+
+    def render(self):
+        """One frame, asynchronous on the current torch stream of scenes[0]'s device; returns (f32 image, u8 image)."""
+        import torch
+
+        seg = C.c_uint64()
+        _lib.check(
+            _lib.lib().mp_render_frame_multi(
+                self._ctxs, self._hs, len(self.scenes), C.byref(self._sampler), C.byref(self._st), self.image.data_ptr(),
+                self.image_u8.data_ptr(), C.byref(seg), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
+            )
+        )
+        self.segments = seg.value
+        return self.image, self.image_u8
+
+
 def render_tile(scene: Scene, sampler: CameraSampler, settings: RenderSettings, tile: ScreenBlock):
     """Worker::render_tile (worker.rs:32-49), synchronous: returns (f32 means [h,w,4], u8 [h,w,4])."""
     bvh = scene.object

@@ -222,3 +222,56 @@ def test_consecutive_seeds_share_no_sample_rays(ctx):
     a = {tuple(r) for r in bits(rays[100]).reshape(-1, 3).tolist()}
     b = {tuple(r) for r in bits(rays[101]).reshape(-1, 3).tolist()}
     assert len(a) == 3 * n and len(a & b) == 0
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_multi_device_behind_the_c_abi(oracle, teapot_oracle_bvh, n):
+    """N GPUs behind the boundary.  mp_render_begin_multi = render()'s worker pool with one host thread per device
+    pulling from the one shared tile queue (machinery.rs:51-116, :205-208); mp_render_frame_multi = device-resident frame, rank
+    r renders tiles r::n, shards gathered to device 0 by peer copies, un-tile there.  On this one-GPU box the n contexts share
+    device 0 (the library allows it for exactly this purpose); the images must equal the oracle's frame bit for bit."""
+    import threading
+
+    import torch
+
+    ctxs = [mp.Context(0) for _ in range(n)]
+    scenes = [mp.Scene(mp.TriangleBvh.with_obj(TEAPOT, c)) for c in ctxs]
+    cam = mp.Camera.teapot_view()
+    res = (200, 136)
+    st = mp.RenderSettings(16, 6, res, seed=SEED)
+    of, ou8, *_ = teapot_oracle_bvh.render_image_mt(oracle.build_sampler(oracle.teapot_camera(), *res), res[0], res[1], 6, SEED, 16, 8)
+    # render(): callbacks from n worker threads
+    lock, started, finished, threads = threading.Lock(), [], [], set()
+
+    def on_start(b):
+        with lock:
+            started.append(b)
+            threads.add(threading.get_ident())
+
+    def on_finish(b, snap):
+        with lock:
+            finished.append((b, snap.finished, snap.total))
+
+    prog = mp.render_multi(scenes, cam, st, on_start, on_finish)
+    prog.wait()
+    assert prog.is_finished() and prog.progress().finished == prog.progress().total == 13 * 9
+    assert np.array_equal(bits(prog.image_f32()), bits(of)) and np.array_equal(prog.image(), ou8)
+    assert len(started) == len(finished) == 13 * 9 and len({(b.min_x, b.min_y) for b in started}) == 13 * 9
+    assert sorted(f[1] for f in finished) == list(range(1, 13 * 9 + 1))
+    assert len(threads) == n  # every device's worker took part
+    prog.close()
+    # device-resident frame
+    mf = mp.MultiDeviceFrame(scenes, cam, st)
+    for _ in range(3):  # frames back to back reuse the shard / gather buffers
+        img, img8 = mf.render()
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(img.cpu().numpy()), bits(of)) and np.array_equal(img8.cpu().numpy(), ou8)
+    assert mf.segments == res[0] * res[1] * 6
+    # build-defined paths through the same entry point
+    st4 = mp.RenderSettings(16, 5, res, seed=SEED, max_depth=4)
+    pf, _, _, _ = teapot_oracle_bvh.render_image_paths_mt(oracle.build_sampler(oracle.teapot_camera(), *res), res[0], res[1], 5, SEED, 4, 16, 8)
+    img4, _ = mp.MultiDeviceFrame(scenes, cam, st4).render()
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(img4.cpu().numpy()), bits(pf))
+    with pytest.raises(mp.MinipathError):
+        mp.MultiDeviceFrame([scenes[0], scenes[0]], cam, st).render()  # the same context twice
