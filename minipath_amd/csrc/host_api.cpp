@@ -76,6 +76,7 @@ struct mp_ctx {
     std::atomic<uint32_t> next_counter{0};
     std::atomic<uint32_t> packet_stack_regs{64};
     std::atomic<uint32_t> packet_samples{0};  // 0 = chosen by the launcher
+    std::atomic<uint32_t> blocks_per_cu{0};   // 0 = as many as fit (diagnostic knob: resident workgroups per CU)
     uint32_t* take_counter() {  // one set of work-queue heads per launch in flight
         return d_counters + static_cast<size_t>(next_counter.fetch_add(1, std::memory_order_relaxed) % kCounters) * kWorkQueues * kWorkQueueStride;
     }
@@ -334,11 +335,11 @@ int upload_scene(mp_scene* s) {
             for (int k = 0; k < 6; k++) nodes_aos[n * 64 + i * 8 + k] = nodes[n * kNodeDwords + k * 8 + i];
             nodes_aos[n * 64 + i * 8 + 6] = nodes[n * kNodeDwords + 48 + i];
         }
-    std::vector<float> tris_aos(np * 96 + 36, 0.0f);  // + tail padding: the triangle loop prefetches up to two ahead
+    std::vector<float> tris_aos(np * 8 * kTriDwords + 4 * kTriDwords, 0.0f);  // + tail padding: the triangle loop prefetches up to two ahead
     std::vector<uint32_t> pkt_valid(np, 0);
     for (size_t p = 0; p < np; p++)
         for (int i = 0; i < 8; i++) {
-            for (int k = 0; k < 9; k++) tris_aos[p * 96 + i * 12 + k] = tris[p * kPacketDwords + k * 8 + i];
+            for (int k = 0; k < 9; k++) tris_aos[(p * 8 + i) * kTriDwords + k] = tris[p * kPacketDwords + k * 8 + i];
             // padding lanes are all-zero quantised triangles with default shading, at the tail of a leaf's last packet
             bool pad = true;
             for (int a = 0; a < 3 && pad; a++)
@@ -541,6 +542,11 @@ int mp_ctx_set_option(mp_ctx* ctx, const char* key, int value) {
     if (std::strcmp(key, "packet_stack_registers") == 0) {
         if (value < 1 || value > 64) return fail(MP_ERR_INVALID, "packet_stack_registers must be in 1..64");
         ctx->packet_stack_regs.store(static_cast<uint32_t>(value));
+        return MP_OK;
+    }
+    if (std::strcmp(key, "blocks_per_cu") == 0) {
+        if (value < 0 || value > 8) return fail(MP_ERR_INVALID, "blocks_per_cu must be in 0..8 (0 = as many as fit)");
+        ctx->blocks_per_cu.store(static_cast<uint32_t>(value));
         return MP_OK;
     }
     if (std::strcmp(key, "packet_samples_in_flight") == 0) {
@@ -762,7 +768,8 @@ int mp_trace_rays(mp_ctx* ctx, const mp_scene* scene, const float* d_ox, const f
     if (scene->ctx != ctx) return fail(MP_ERR_INVALID, "scene belongs to another context");
     DeviceGuard g(ctx->device);
     std::string err;
-    int rc = launch_trace_rays(scene->dev, d_ox, d_oy, d_oz, d_dx, d_dy, d_dz, n, *hits, ctx->cu_count, stream, err);
+    const uint32_t bpc = ctx->blocks_per_cu.load();
+    int rc = launch_trace_rays(scene->dev, d_ox, d_oy, d_oz, d_dx, d_dy, d_dz, n, *hits, ctx->cu_count * (bpc ? static_cast<int>(bpc) : 8) / 8, stream, err);
     if (rc) return fail(rc, err);
     return MP_OK;
     });

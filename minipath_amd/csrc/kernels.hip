@@ -178,7 +178,7 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0;
     // Lane li fetches child li / triangle li as whole 16-byte words from the AoS copies (two loads per node, three per packet)
     const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes_aos);
-    const float4* __restrict__ tris4 = reinterpret_cast<const float4*>(sc.tris_aos);
+    const float* __restrict__ tris = sc.tris_aos;
     float best_t = FLT_MAX;                 // best.t, group-uniform (ray_bvh_intersection.rs:34-37)
     float tl = FLT_MAX, ul = 0, vl = 0;     // this lane's earliest closest candidate
     uint32_t pkl = kNoPrim, seql = 0;
@@ -258,9 +258,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
         }
         // -- B: one leaf packet per iteration (:104-140) ; lane li = triangle li
         if (slot >= 0 && pk < pk_end) {
-            const float4* tp = tris4 + (static_cast<size_t>(pk) * 8 + li) * 3;
-            const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];  // {v0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, -, -, -}
-            const float v0x = q0.x, v0y = q0.y, v0z = q0.z, e1x = q0.w, e1y = q1.x, e1z = q1.y, e2x = q1.z, e2y = q1.w, e2z = q2.x;
+            const float* tp = tris + (static_cast<size_t>(pk) * 8 + li) * kTriDwords;  // 36-byte records: v0, e1, e2
+            const float v0x = tp[0], v0y = tp[1], v0z = tp[2], e1x = tp[3], e1y = tp[4], e1z = tp[5], e2x = tp[6], e2y = tp[7], e2z = tp[8];
             // triangle.rs:183-217
             float hx = fms(dy, e2z, dz * e2y), hy = fms(dz, e2x, dx * e2z), hz = fms(dx, e2y, dy * e2x);
             float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
@@ -306,7 +305,7 @@ __device__ __forceinline__ uint32_t resolve_normal(const DevScene& sc, uint32_t 
     float nx, ny, nz;
     if (as_u(c.y) != 0u) {
         // flat: Triangle::normal (triangle.rs:141-144), unfused cross of the decompressed edges
-        const float* tp = sc.tris_aos + static_cast<size_t>(prim) * 12;
+        const float* tp = sc.tris_aos + static_cast<size_t>(prim) * kTriDwords;
         float e1x = tp[3], e1y = tp[4], e1z = tp[5], e2x = tp[6], e2y = tp[7], e2z = tp[8];
         nx = e1y * e2z - e1z * e2y;
         ny = e1z * e2x - e1x * e2z;
@@ -700,7 +699,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
             // strict `<`.  Padding (only at the tail of the last packet) can never be accepted and is not visited.
             const uint32_t first = link >> 3, count = link & 7u;
             const uint32_t n_real = (count - 1u) * 8u + __builtin_amdgcn_readfirstlane(nvalid[first + count - 1u]);
-            kfp tp = tris + static_cast<size_t>(first) * 96;
+            kfp tp = tris + static_cast<size_t>(first) * (8 * kTriDwords);
             uint64_t changed = 0;  // lanes that accepted a hit in this leaf
             // One triangle test; all predicates are lane masks combined with `&` (no short-circuit control flow).
             auto test = [&](const float v0x, const float v0y, const float v0z, const float e1x, const float e1y, const float e1z,
@@ -736,13 +735,13 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
             uint32_t i = 0;
             const uint32_t base = first * 8u;
             for (;;) {
-                const float b0 = tp[12], b1 = tp[13], b2 = tp[14], b3 = tp[15], b4 = tp[16], b5 = tp[17], b6 = tp[18], b7 = tp[19], b8 = tp[20];
+                const float b0 = tp[9], b1 = tp[10], b2 = tp[11], b3 = tp[12], b4 = tp[13], b5 = tp[14], b6 = tp[15], b7 = tp[16], b8 = tp[17];
                 test(a0, a1, a2, a3, a4, a5, a6, a7, a8, base + i);
                 if (++i == n_real) break;
-                a0 = tp[24]; a1 = tp[25]; a2 = tp[26]; a3 = tp[27]; a4 = tp[28]; a5 = tp[29]; a6 = tp[30]; a7 = tp[31]; a8 = tp[32];
+                a0 = tp[18]; a1 = tp[19]; a2 = tp[20]; a3 = tp[21]; a4 = tp[22]; a5 = tp[23]; a6 = tp[24]; a7 = tp[25]; a8 = tp[26];
                 test(b0, b1, b2, b3, b4, b5, b6, b7, b8, base + i);
                 if (++i == n_real) break;
-                tp += 24;
+                tp += 2 * kTriDwords;
             }
             if (changed != 0) st.all_stale();  // every entry still on the stack predates this change
         }

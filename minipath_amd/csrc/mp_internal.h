@@ -62,10 +62,10 @@ int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err);
 
 // ---- device scene ("traversal format") -------------------------------------------------------
 // nodes_aos : inner_count x 8 children x 8 dwords {minx,miny,minz,maxx,maxy,maxz,link,0}: absolute decompressed child boxes.
-// tris_aos  : packet_count x 8 triangles x 12 dwords {v0.xyz,e1.xyz,e2.xyz,0,0,0}: decompressed v0 and the edges e1=v1-v0,
-//             e2=v2-v0 of triangle.rs:195-196 (+ 36 dwords of tail padding: the packet walk fetches two triangles ahead).
-//             The packet walk reads both through the scalar unit (wave-uniform), the 8-lane-group walk as one 16-byte word per
-//             lane (lane i = child i / triangle i).
+// tris_aos  : packet_count x 8 triangles x kTriDwords (9) dwords {v0.xyz,e1.xyz,e2.xyz}: decompressed v0 and the edges e1=v1-v0,
+//             e2=v2-v0 of triangle.rs:195-196 (+ 3 records of tail padding: the packet walk fetches two triangles ahead).
+//             The packet walk reads both through the scalar unit (wave-uniform), the 8-lane-group walk with per-lane vector loads
+//             (lane i = child i / triangle i).
 // pkt_valid : real (unpadded) triangles of each packet.
 // shade     : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) material(u32 bits) pad.  48 B per triangle slot.
 // vidx/vtex : for the full HitRecord (texture_coords).
@@ -98,6 +98,7 @@ struct DevScene {
 constexpr uint32_t kWorkQueues = 8;
 constexpr uint32_t kWorkQueueStride = 32;  // dwords
 
+constexpr int kTriDwords = 9;      // device triangle record: v0.xyz, e1.xyz, e2.xyz, densely packed (36 B: 25 % fewer cache lines than a 48-B padded record)
 constexpr int kNodeDwords = 56;    // host staging rows: minx..maxz (8 floats each) + link[8]
 constexpr int kPacketDwords = 72;  // host staging rows: v0.xyz, e1.xyz, e2.xyz (8 floats each)
 
