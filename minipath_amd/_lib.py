@@ -132,6 +132,7 @@ class HitsSoA(C.Structure):
         ("d_normal", C.c_void_p),
         ("d_tex", C.c_void_p),
         ("d_material", C.c_void_p),
+        ("d_instance", C.c_void_p),
     ]
 
 
@@ -171,6 +172,7 @@ SIGNATURES = {
     "mp_scene_set_materials": (C.c_int, [C.c_void_p, C.POINTER(Material), C.c_uint32, C.c_float]),
     "mp_scene_material_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "mp_scene_sphere": (C.c_int, [C.c_void_p, _f3, C.c_float, C.POINTER(C.c_void_p)]),
+    "mp_scene_instances": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "mp_scene_destroy": (None, [C.c_void_p]),
     "mp_scene_info_get": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
     "mp_scene_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -155,6 +155,9 @@ struct mp_scene {
     void* d_tris_aos = nullptr;
     void* d_pkt_valid = nullptr;
     void* d_materials = nullptr;
+    void* d_inst = nullptr;               // mp_scene_instances: translations
+    const mp_scene* inst_of = nullptr;    // ... of this object, whose device arrays this scene borrows
+    std::vector<float> inst_t;
     std::vector<mp_material> materials{mp_material{0.75f, 0.0f}};  // build-defined path extension defaults
     float sky = 1.0f;
     uint32_t material_count = 1;  // max TriangleShadingData.material + 1
@@ -672,6 +675,50 @@ int mp_scene_from_arrays(mp_ctx* ctx, const mp_bvh_desc* desc, mp_scene** out) {
     });
 }
 
+int mp_scene_instances(mp_ctx* ctx, const mp_scene* object, const float* translations, uint32_t n, mp_scene** out) {
+    return guarded([&]() -> int {
+    if (!object || !translations || !out || n == 0) return fail(MP_ERR_INVALID, "bad argument");
+    if (object->dev.kind != 0u || object->inst_of) return fail(MP_ERR_UNSUPPORTED, "instances are made of a TriangleBvh scene");
+    if (object->ctx != ctx) return fail(MP_ERR_INVALID, "object belongs to another context");
+    if (n > (1u << 20)) return fail(MP_ERR_INVALID, "too many instances");
+    auto s = std::make_unique<mp_scene>();
+    s->ctx = ctx;
+    s->inst_of = object;
+    s->inst_t.assign(translations, translations + static_cast<size_t>(n) * 3);
+    s->host.root = object->host.root;
+    s->host.depth = object->host.depth;
+    s->host.vertex_count = object->host.vertex_count;
+    s->host.triangle_count = object->host.triangle_count;
+    s->host.material_names = object->host.material_names;
+    for (int k = 0; k < 3; k++) {  // get_bounding_box: union of the translated boxes
+        float mn = 0, mx = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const float a = object->host.bbox.mn[k] + translations[3 * i + k], b = object->host.bbox.mx[k] + translations[3 * i + k];
+            mn = i ? std::fmin(mn, a) : a;
+            mx = i ? std::fmax(mx, b) : b;
+        }
+        s->host.bbox.mn[k] = mn;
+        s->host.bbox.mx[k] = mx;
+    }
+    s->materials = object->materials;
+    s->sky = object->sky;
+    s->material_count = object->material_count;
+    s->dev = object->dev;
+    s->d_materials = object->d_materials;
+    s->dev.inst_count = n;
+    if (ctx) {
+        DeviceGuard g(ctx->device);
+        MP_HIP(hipMalloc(&s->d_inst, static_cast<size_t>(n) * 12));
+        hipError_t e = hipMemcpy(s->d_inst, translations, static_cast<size_t>(n) * 12, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(s->d_inst); return hip_fail(e, "hipMemcpy(instances)"); }
+        s->dev.inst_t = static_cast<const float*>(s->d_inst);
+        s->device_bytes = static_cast<uint64_t>(n) * 12;
+    }
+    *out = s.release();
+    return MP_OK;
+    });
+}
+
 int mp_scene_set_materials(mp_scene* scene, const mp_material* table, uint32_t n, float sky_radiance) {
     return guarded([&]() -> int {
     if (!scene || !table) return fail(MP_ERR_INVALID, "NULL argument");
@@ -685,7 +732,8 @@ int mp_scene_set_materials(mp_scene* scene, const mp_material* table, uint32_t n
         MP_HIP(hipMalloc(&d_new, std::max<size_t>(16, n * sizeof(mp_material))));
         hipError_t e = hipMemcpy(d_new, scene->materials.data(), n * sizeof(mp_material), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(d_new); return hip_fail(e, "hipMemcpy(materials)"); }
-        if (scene->d_materials) (void)hipFree(scene->d_materials);  // hipFree waits for the device
+        if (scene->d_materials && !(scene->inst_of && scene->d_materials == scene->inst_of->d_materials))
+            (void)hipFree(scene->d_materials);  // hipFree waits for the device
         scene->d_materials = d_new;
         scene->dev.materials = static_cast<const float*>(d_new);
         scene->dev.sky = sky_radiance;
@@ -714,6 +762,15 @@ int mp_scene_sphere(mp_ctx* ctx, const float center[3], float radius, mp_scene**
 
 void mp_scene_destroy(mp_scene* s) {
     if (!s) return;
+    if (s->inst_of) {  // an instanced scene owns only its translation array (and, if re-set, its material table)
+        if (s->ctx) {
+            DeviceGuard g(s->ctx->device);
+            if (s->d_inst) (void)hipFree(s->d_inst);
+            if (s->d_materials && s->d_materials != s->inst_of->d_materials) (void)hipFree(s->d_materials);
+        }
+        delete s;
+        return;
+    }
     if (s->ctx) {
         DeviceGuard g(s->ctx->device);
         for (void* p : {s->d_shade, s->d_vidx, s->d_vtex, s->d_nodes_aos, s->d_tris_aos, s->d_pkt_valid, s->d_materials})
@@ -726,8 +783,8 @@ int mp_scene_info_get(const mp_scene* s, mp_scene_info* out) {
     return guarded([&]() -> int {
     if (!s || !out) return fail(MP_ERR_INVALID, "NULL argument");
     out->root_link = s->host.root;
-    out->inner_count = static_cast<uint32_t>(s->host.inner.size());
-    out->packet_count = static_cast<uint32_t>(s->host.packets.size());
+    out->inner_count = static_cast<uint32_t>((s->inst_of ? s->inst_of->host : s->host).inner.size());
+    out->packet_count = static_cast<uint32_t>((s->inst_of ? s->inst_of->host : s->host).packets.size());
     out->vertex_count = s->host.vertex_count;
     out->triangle_count = s->host.triangle_count;
     out->depth = s->host.depth;
@@ -747,7 +804,7 @@ int mp_scene_export(const mp_scene* s, void* inner_nodes, void* packets, void* t
                     float* vertex_tex, uint32_t* tri_material) {
     return guarded([&]() -> int {
     if (!s) return fail(MP_ERR_INVALID, "scene is NULL");
-    const HostBvh& h = s->host;
+    const HostBvh& h = s->inst_of ? s->inst_of->host : s->host;
     if (inner_nodes && !h.inner.empty()) std::memcpy(inner_nodes, h.inner.data(), h.inner.size() * sizeof(InnerNodeRef));
     if (packets && !h.packets.empty()) std::memcpy(packets, h.packets.data(), h.packets.size() * sizeof(TriPacketRef));
     if (tri_shading && !h.shading.empty()) std::memcpy(tri_shading, h.shading.data(), h.shading.size() * sizeof(TriShadingRef));

@@ -296,6 +296,14 @@ __device__ __forceinline__ bool may_hit_scene(const DevScene& sc, const Ray& r) 
     return t1 <= t2;
 }
 
+// Build-defined instanced Object (mp_scene_instances): the ray in instance k's frame (origin - translation; direction unchanged).
+__device__ __forceinline__ void instance_ray(const DevScene& sc, uint32_t k, const Ray& r, Ray& rk) {
+    rk = r;
+    if (sc.inst_count) {
+        rk.ox = r.ox - sc.inst_t[3 * k]; rk.oy = r.oy - sc.inst_t[3 * k + 1]; rk.oz = r.oz - sc.inst_t[3 * k + 2];
+    }
+}
+
 // Hit resolve + shade: tail of intersect (ray_bvh_intersection.rs:66-95) and render_sample (worker.rs:59-65).
 // Returns |dot(ray.direction, normal)|.
 // Returns TriangleShadingData.material of the triangle (mod.rs:44; 0 for everything the reference builds).
@@ -472,27 +480,37 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
                 if (P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) chunk_flush(P, off, inpix && sub == 0, acc);
                 continue;
             }
-            // compaction of the lanes whose ray can reach the scene into the wave's ray queue
-            const bool queued = act && may_hit_scene(P.scene, r);
-            const uint64_t am = __ballot(queued);
-            const int n = __popcll(am), rank = __popcll(am & lanes_lt);
-            if (queued) {
-                q[0 * 64 + rank] = r.ox; q[1 * 64 + rank] = r.oy; q[2 * 64 + rank] = r.oz;
-                q[3 * 64 + rank] = r.dx; q[4 * 64 + rank] = r.dy; q[5 * 64 + rank] = r.dz;
-            }
-            wave_lds_sync();
-            trace_wave(P.scene, q, stack, n);
-            float c = 0.0f, h = 0.0f;
-            if (queued) {
-                uint32_t prim = as_u(q[1 * 64 + rank]);
-                if (prim != kNoPrim) {
-                    float nn[3];
-                    resolve_normal(P.scene, prim, q[2 * 64 + rank], q[3 * 64 + rank], nn);
-                    c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60
-                    h = 1.0f;
+            // per object instance (one pass for a plain TriangleBvh): compaction of the lanes whose ray can reach the object into
+            // the wave's ray queue, group traversal, closest hit over the instances with a strict `<`
+            float bt = FLT_MAX, bu = 0.0f, bv = 0.0f;
+            uint32_t bprim = kNoPrim;
+            const uint32_t ninst = P.scene.inst_count ? P.scene.inst_count : 1u;
+            for (uint32_t k = 0; k < ninst; k++) {
+                Ray rk;
+                instance_ray(P.scene, k, r, rk);
+                const bool queued = act && may_hit_scene(P.scene, rk);
+                const uint64_t am = __ballot(queued);
+                const int n = __popcll(am), rank = __popcll(am & lanes_lt);
+                if (queued) {
+                    q[0 * 64 + rank] = rk.ox; q[1 * 64 + rank] = rk.oy; q[2 * 64 + rank] = rk.oz;
+                    q[3 * 64 + rank] = rk.dx; q[4 * 64 + rank] = rk.dy; q[5 * 64 + rank] = rk.dz;
                 }
+                wave_lds_sync();
+                trace_wave(P.scene, q, stack, n);
+                if (queued) {
+                    const uint32_t prim = as_u(q[1 * 64 + rank]);
+                    const float t = q[0 * 64 + rank];
+                    if (prim != kNoPrim && t < bt) { bt = t; bprim = prim; bu = q[2 * 64 + rank]; bv = q[3 * 64 + rank]; }
+                }
+                wave_lds_sync();
             }
-            wave_lds_sync();
+            float c = 0.0f, h = 0.0f;
+            if (bprim != kNoPrim) {
+                float nn[3];
+                resolve_normal(P.scene, bprim, bu, bv, nn);
+                c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60
+                h = 1.0f;
+            }
             // pixel_sum += sample, strictly in sample order (worker.rs:41-43); inactive samples add +0.0 (exact)
 #pragma unroll
             for (int j = 0; j < S; j++) {
@@ -973,8 +991,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                 if (alive_m == 0) break;
                 segs += static_cast<unsigned long long>(__popcll(alive_m));
                 h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
-                const bool go = alive && may_hit_scene(P.scene, r);
-                if (depth == 1) {
+                if (depth == 1 && P.scene.inst_count == 0u) {
+                    const bool go = alive && may_hit_scene(P.scene, r);
                     if (__ballot(go) != 0) {
                         RegStack rst(nullptr, lane);
                         HybridStack hst(reinterpret_cast<float*>(stack), lane, P.scene.stack_cap, P.scene.packet_stack_regs);
@@ -982,21 +1000,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                         else trace_packet<(S >= 8)>(P.scene, r, go, rst, h);
                     }
                 } else {
-                    const uint64_t gm = __ballot(go);
-                    const int n = __popcll(gm), rank = __popcll(gm & lanes_lt);
-                    if (go) {
-                        q[0 * 64 + rank] = r.ox; q[1 * 64 + rank] = r.oy; q[2 * 64 + rank] = r.oz;
-                        q[3 * 64 + rank] = r.dx; q[4 * 64 + rank] = r.dy; q[5 * 64 + rank] = r.dz;
-                            }
-                    wave_lds_sync();
-                    trace_wave(P.scene, q, stack, n);
-                    if (go) {
-                        h.t = q[0 * 64 + rank];
-                        h.prim = as_u(q[1 * 64 + rank]);
-                        h.u = q[2 * 64 + rank];
-                        h.v = q[3 * 64 + rank];
+                    // bounce rays (and every ray of an instanced object): 8-lane-group traversal, once per object instance
+                    const uint32_t ninst = P.scene.inst_count ? P.scene.inst_count : 1u;
+                    for (uint32_t k = 0; k < ninst; k++) {
+                        Ray rk;
+                        instance_ray(P.scene, k, r, rk);
+                        const bool go = alive && may_hit_scene(P.scene, rk);
+                        const uint64_t gm = __ballot(go);
+                        const int n = __popcll(gm), rank = __popcll(gm & lanes_lt);
+                        if (go) {
+                            q[0 * 64 + rank] = rk.ox; q[1 * 64 + rank] = rk.oy; q[2 * 64 + rank] = rk.oz;
+                            q[3 * 64 + rank] = rk.dx; q[4 * 64 + rank] = rk.dy; q[5 * 64 + rank] = rk.dz;
+                        }
+                        wave_lds_sync();
+                        trace_wave(P.scene, q, stack, n);
+                        if (go) {
+                            const uint32_t prim = as_u(q[1 * 64 + rank]);
+                            const float t = q[0 * 64 + rank];
+                            if (prim != kNoPrim && t < h.t) { h.t = t; h.prim = prim; h.u = q[2 * 64 + rank]; h.v = q[3 * 64 + rank]; }
+                        }
+                        wave_lds_sync();
                     }
-                    wave_lds_sync();
                 }
                 if (alive) alive = path_vertex(P.scene, h, depth, P.max_depth, rng, r, L, thr, primary_hit);
             }
@@ -1325,22 +1349,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     if (P.hits.d_tex) P.hits.d_tex[i * 3 + k] = 0.0f;
                 }
                 if (P.hits.d_material) P.hits.d_material[i] = 0u;
+                if (P.hits.d_instance) P.hits.d_instance[i] = 0u;
             }
             continue;
         }
-        const bool queued = act && may_hit_scene(P.scene, r0);
-        const uint64_t am = __ballot(queued);
-        const int n = __popcll(am), rank = __popcll(am & ((1ull << lane) - 1ull));
-        if (queued) {
-            q[0 * 64 + rank] = r0.ox; q[1 * 64 + rank] = r0.oy; q[2 * 64 + rank] = r0.oz;
-            q[3 * 64 + rank] = r0.dx; q[4 * 64 + rank] = r0.dy; q[5 * 64 + rank] = r0.dz;
+        float t = FLT_MAX, u = 0.0f, v = 0.0f;
+        uint32_t prim = kNoPrim, inst = 0u;
+        const uint32_t ninst = P.scene.inst_count ? P.scene.inst_count : 1u;
+        for (uint32_t k = 0; k < ninst; k++) {  // one pass per object instance (one for a plain TriangleBvh)
+            Ray rk;
+            instance_ray(P.scene, k, r0, rk);
+            const bool queued = act && may_hit_scene(P.scene, rk);
+            const uint64_t am = __ballot(queued);
+            const int n = __popcll(am), rank = __popcll(am & ((1ull << lane) - 1ull));
+            if (queued) {
+                q[0 * 64 + rank] = rk.ox; q[1 * 64 + rank] = rk.oy; q[2 * 64 + rank] = rk.oz;
+                q[3 * 64 + rank] = rk.dx; q[4 * 64 + rank] = rk.dy; q[5 * 64 + rank] = rk.dz;
+            }
+            wave_lds_sync();
+            trace_wave(P.scene, q, stack, n);
+            if (queued) {
+                const uint32_t pk = as_u(q[1 * 64 + rank]);
+                const float tk = q[0 * 64 + rank];
+                if (pk != kNoPrim && tk < t) { t = tk; prim = pk; u = q[2 * 64 + rank]; v = q[3 * 64 + rank]; inst = k; }
+            }
+            wave_lds_sync();
         }
-        wave_lds_sync();
-        trace_wave(P.scene, q, stack, n);
         if (act) {
-            float t = queued ? q[0 * 64 + rank] : FLT_MAX;
-            uint32_t prim = queued ? as_u(q[1 * 64 + rank]) : kNoPrim;
-            float u = queued ? q[2 * 64 + rank] : 0.0f, v = queued ? q[3 * 64 + rank] : 0.0f;
             if (P.hits.d_t) P.hits.d_t[i] = t;
             if (P.hits.d_prim) P.hits.d_prim[i] = prim;
             if (P.hits.d_u) P.hits.d_u[i] = u;
@@ -1366,8 +1401,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 }
                 if (P.hits.d_material) P.hits.d_material[i] = mat;
             }
+            if (P.hits.d_instance) P.hits.d_instance[i] = inst;
         }
-        wave_lds_sync();
     }
 }
 
@@ -1505,7 +1540,7 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         else hipLaunchKernelGGL(render_paths_kernel<1>, dim3(grid), dim3(256), lds, st, P);
         return check(hipGetLastError(), "render_paths_kernel launch", err);
     }
-    if (L.traversal == 1) {
+    if (L.traversal == 1 || L.scene.inst_count != 0u) {  // instanced objects are walked per instance by the 8-lane groups
         const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * 8));
         hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);
         return check(hipGetLastError(), "render_tiles_kernel launch", err);
@@ -1546,7 +1581,7 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
 int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::string& err) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (L.n_tiles == 0) return MP_OK;
-    if (L.scene.kind != 0u || L.max_depth == 0) { err = "the staged path evaluation needs MP_FLAG_PATHS and a TriangleBvh scene"; return MP_ERR_UNSUPPORTED; }
+    if (L.scene.kind != 0u || L.max_depth == 0 || L.scene.inst_count != 0u) { err = "the staged path evaluation needs MP_FLAG_PATHS and a plain TriangleBvh scene"; return MP_ERR_UNSUPPORTED; }
     WfParams P;
     P.scene = L.scene;
     P.gen.s = L.sampler;

@@ -81,6 +81,8 @@ struct DevScene {
     const float* vtex = nullptr;     // nv*3
     const float* materials = nullptr;  // build-defined path extension: {albedo, emission} per material id (device)
     float sky = 1.0f;                  // ... and the sky radiance
+    uint32_t inst_count = 0;           // build-defined instanced Object: translations (device, xyz per instance); 0 = plain BVH
+    const float* inst_t = nullptr;
     uint32_t root = MP_LINK_NULL;
     uint32_t inner_count = 0;
     uint32_t packet_count = 0;

@@ -153,13 +153,15 @@ class TriangleBvh:
             "u": torch.empty(n, dtype=torch.float32, device=dev),
             "v": torch.empty(n, dtype=torch.float32, device=dev),
         }
-        hits = _lib.HitsSoA(out["t"].data_ptr(), out["prim"].data_ptr(), out["u"].data_ptr(), out["v"].data_ptr(), None, None, None, None)
+        hits = _lib.HitsSoA(out["t"].data_ptr(), out["prim"].data_ptr(), out["u"].data_ptr(), out["v"].data_ptr(), None, None, None, None, None)
         if full:
             for k in ("point", "normal", "tex"):
                 out[k] = torch.empty((n, 3), dtype=torch.float32, device=dev)
             out["material"] = torch.empty(n, dtype=torch.int32, device=dev)
             hits.d_point, hits.d_normal, hits.d_tex = out["point"].data_ptr(), out["normal"].data_ptr(), out["tex"].data_ptr()
             hits.d_material = out["material"].data_ptr()
+            out["instance"] = torch.empty(n, dtype=torch.int32, device=dev)
+            hits.d_instance = out["instance"].data_ptr()
         st = stream if stream is not None else torch.cuda.current_stream(dev).cuda_stream
         _lib.check(
             _lib.lib().mp_trace_rays(
@@ -179,6 +181,22 @@ class TriangleBvh:
             self.close()
         except Exception:
             pass
+
+
+class Instances(TriangleBvh):
+    """BUILD-DEFINED Object (scene/mod.rs:7-10 `trait Object`; the reference's Scene holds one object, no transforms): translated
+    instances of one TriangleBvh (mp_scene_instances).  Shares the object's device arrays: keeps a reference to it."""
+
+    def __init__(self, obj: TriangleBvh, translations):
+        t = np.ascontiguousarray(translations, np.float32).reshape(-1, 3)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().mp_scene_instances(obj.ctx.handle if obj.ctx else None, obj.handle, t.ctypes.data, t.shape[0], C.byref(h)))
+        super().__init__(h, obj.ctx)
+        self.object, self.translations = obj, t
+
+    def close(self):
+        super().close()  # before the object it borrows from
+        self.object = None
 
 
 class Sphere(TriangleBvh):

@@ -538,6 +538,8 @@ struct mpo_bvh {
     /* build-defined path extension: material table + sky radiance (see render_sample_paths_impl) */
     mpo_material *mats; uint32_t n_mats;
     float sky;
+    /* build-defined Object: translated instances of this BVH (see scene_intersect); 0 = the plain TriangleBvh */
+    uint32_t n_inst; float *inst_t;
 };
 
 typedef struct { float mn[3], mx[3]; } box3;
@@ -945,7 +947,7 @@ uint32_t mpo_bvh_material_count(const mpo_bvh *b) {
 
 void mpo_bvh_free(mpo_bvh *b) {
     if (!b) return;
-    free(b->inner); free(b->packets); free(b->shading); free(b->vnormal); free(b->vtex); free(b->material); free(b->mats);
+    free(b->inner); free(b->packets); free(b->shading); free(b->vnormal); free(b->vtex); free(b->material); free(b->mats); free(b->inst_t);
     free(b);
 }
 
@@ -1122,7 +1124,7 @@ static inline void op_rec(uint8_t v) {
     if (g_ops && g_ops_n < g_ops_cap) { if (g_links) g_links[g_ops_n] = g_cur_link; g_ops[g_ops_n++] = v; }
 }
 
-static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache *st, mpo_hit *out, mpo_counters *cnt) {
+static void bvh_intersect_one(const mpo_bvh *b, const mpo_ray *ray, stack_cache *st, mpo_hit *out, mpo_counters *cnt) {
     st->n = 0;
     stack_entry root;
     root.link = b->root;
@@ -1217,11 +1219,46 @@ static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache
     out->material = b->material[best.prim]; /* always 0 in the reference (building.rs:201) */
 }
 
+/* BUILD-DEFINED Object (scene/mod.rs:7-10 `trait Object`; the reference has one object per Scene and no transforms): a list of
+ * instances {this TriangleBvh, translation}.  intersect = for every instance in order: the object's own intersect with the ray
+ * moved into the instance's frame (origin - translation; direction, hence t, unchanged), closest wins with a strict `<` (the
+ * first instance keeps ties); HitRecord.point = point_at(t) of the WORLD ray; normal / tex / material are the object's. */
+static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache *st, mpo_hit *out, mpo_counters *cnt) {
+    if (b->n_inst == 0) { bvh_intersect_one(b, ray, st, out, cnt); return; }
+    mpo_hit best;
+    memset(&best, 0, sizeof(best));
+    best.prim = MPO_NO_TRIANGLE;
+    best.t = FLT_MAX;
+    for (uint32_t k = 0; k < b->n_inst; k++) {
+        mpo_ray r2 = *ray;
+        for (int i = 0; i < 3; i++) r2.o[i] = ray->o[i] - b->inst_t[3 * k + i];
+        mpo_hit h;
+        bvh_intersect_one(b, &r2, st, &h, cnt);
+        if (cnt) cnt->rays--; /* one Object::intersect call of the scene's object, however many instances it holds */
+        if (h.hit && h.t < best.t) { best = h; best.instance = k; }
+    }
+    if (cnt) cnt->rays++;
+    if (best.hit) mpo_ray_point_at(ray, best.t, best.point);
+    *out = best;
+}
+
+int mpo_bvh_set_instances(mpo_bvh *b, const float *translations, uint32_t n) {
+    if (!b || (n && !translations)) return 0;
+    free(b->inst_t);
+    b->inst_t = NULL;
+    b->n_inst = n;
+    if (n) {
+        b->inst_t = malloc((size_t)n * 3 * sizeof(float));
+        memcpy(b->inst_t, translations, (size_t)n * 3 * sizeof(float));
+    }
+    return 1;
+}
+
 size_t mpo_bvh_intersect_ops(const mpo_bvh *b, const mpo_ray *ray, uint8_t *ops, uint32_t *links, size_t cap) {
     stack_cache st = {0};
     mpo_hit h;
     g_ops = ops; g_links = links; g_ops_cap = cap; g_ops_n = 0;
-    bvh_intersect_impl(b, ray, &st, &h, NULL);
+    bvh_intersect_one(b, ray, &st, &h, NULL);
     size_t n = g_ops_n;
     g_ops = NULL; g_links = NULL; g_ops_cap = 0; g_ops_n = 0;
     free(st.e);
@@ -1232,6 +1269,15 @@ void mpo_bvh_intersect(const mpo_bvh *b, const mpo_ray *ray, mpo_hit *out, mpo_c
     stack_cache st = {0};
     bvh_intersect_impl(b, ray, &st, out, cnt);
     free(st.e);
+}
+
+static _Thread_local uint32_t *g_trace_inst = NULL;
+void mpo_trace_rays_inst(const mpo_bvh *b, const float *ox, const float *oy, const float *oz, const float *dx,
+                         const float *dy, const float *dz, uint64_t n, float *t, uint32_t *prim, float *u, float *v,
+                         uint32_t *inst) {
+    g_trace_inst = inst;
+    mpo_trace_rays(b, ox, oy, oz, dx, dy, dz, n, t, prim, u, v, NULL);
+    g_trace_inst = NULL;
 }
 
 void mpo_trace_rays(const mpo_bvh *b, const float *ox, const float *oy, const float *oz, const float *dx,
@@ -1247,6 +1293,7 @@ void mpo_trace_rays(const mpo_bvh *b, const float *ox, const float *oy, const fl
         t[i] = h.t;
         prim[i] = h.hit ? (uint32_t)h.prim : 0xFFFFFFFFu;
         u[i] = h.u; v[i] = h.v;
+        if (g_trace_inst) g_trace_inst[i] = h.hit ? h.instance : 0u;
     }
     free(st.e);
 }

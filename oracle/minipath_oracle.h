@@ -91,6 +91,7 @@ typedef struct {
     float normal[3];    /* HitRecord.normal (unit) */
     float tex[3];       /* HitRecord.texture_coords */
     uint64_t material;
+    uint32_t instance;  /* build-defined instanced Object: which instance was hit (0 otherwise) */
 } mpo_hit;
 
 typedef struct {
@@ -170,6 +171,9 @@ mpo_bvh *mpo_bvh_from_arrays(const mpo_inner_node *inner, uint32_t n_inner, cons
 int mpo_bvh_set_materials(mpo_bvh *b, const mpo_material *table, uint32_t n, float sky);
 const uint32_t *mpo_bvh_tri_material(const mpo_bvh *b);       /* packet_count*8 entries */
 uint32_t mpo_bvh_material_count(const mpo_bvh *b);            /* max id + 1 */
+/* BUILD-DEFINED Object: n translated instances of this BVH (n*3 floats; n = 0 restores the plain TriangleBvh).  Every
+ * intersect / render entry point then treats the list as the scene's object (see scene semantics in the .c file). */
+int mpo_bvh_set_instances(mpo_bvh *b, const float *translations, uint32_t n);
 void mpo_bvh_free(mpo_bvh *b);
 uint32_t mpo_bvh_root(const mpo_bvh *b);
 void mpo_bvh_bbox(const mpo_bvh *b, float bmin[3], float bmax[3]);
@@ -191,6 +195,10 @@ size_t mpo_bvh_intersect_ops(const mpo_bvh *b, const mpo_ray *ray, uint8_t *ops,
 void mpo_trace_rays(const mpo_bvh *b, const float *ox, const float *oy, const float *oz, const float *dx,
                     const float *dy, const float *dz, uint64_t n, float *t, uint32_t *prim, float *u, float *v,
                     mpo_counters *cnt);
+
+void mpo_trace_rays_inst(const mpo_bvh *b, const float *ox, const float *oy, const float *oz, const float *dx,
+                         const float *dy, const float *dz, uint64_t n, float *t, uint32_t *prim, float *u, float *v,
+                         uint32_t *inst);
 
 /* ---- renderer/worker.rs --------------------------------------------------------------------------- */
 /* render_sample :51-66 with the build-defined seeded RNG: returns rgba */

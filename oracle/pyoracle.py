@@ -76,6 +76,7 @@ class Hit(C.Structure):
         ("normal", C.c_float * 3),
         ("tex", C.c_float * 3),
         ("material", C.c_uint64),
+        ("instance", C.c_uint32),
     ]
 
 
@@ -156,6 +157,9 @@ def lib() -> C.CDLL:
     L.mpo_bvh_material_count.argtypes = [C.c_void_p]
     L.mpo_bvh_material_count.restype = C.c_uint32
     L.mpo_set_chunked_sum.argtypes = [C.c_int]
+    L.mpo_bvh_set_instances.argtypes = [C.c_void_p, f32p, C.c_uint32]
+    L.mpo_bvh_set_instances.restype = C.c_int
+    L.mpo_trace_rays_inst.argtypes = [C.c_void_p] + [f32p] * 6 + [C.c_uint64, f32p, u32p, f32p, f32p, u32p]
     L.mpo_seed_mix.argtypes = [C.c_uint64]
     L.mpo_seed_mix.restype = C.c_uint64
     L.mpo_bvh_free.argtypes = [C.c_void_p]
@@ -329,6 +333,22 @@ class Bvh:
         t = np.ascontiguousarray(table, np.float32).reshape(-1, 2)
         if not lib().mpo_bvh_set_materials(self.h, _f32p(t), t.shape[0], C.c_float(sky)):
             raise RuntimeError("material id of a triangle outside the table")
+
+    def set_instances(self, translations) -> None:
+        """BUILD-DEFINED Object: translated instances of this BVH ([] restores the plain TriangleBvh)."""
+        t = np.ascontiguousarray(translations, np.float32).reshape(-1, 3)
+        if not lib().mpo_bvh_set_instances(self.h, _f32p(t) if t.shape[0] else None, t.shape[0]):
+            raise RuntimeError("set_instances failed")
+
+    def trace_inst(self, o: np.ndarray, d: np.ndarray):
+        """trace() plus the instance index of every hit."""
+        o = np.ascontiguousarray(o, np.float32); d = np.ascontiguousarray(d, np.float32)
+        n = o.shape[0]
+        cols = [np.ascontiguousarray(o[:, k]) for k in range(3)] + [np.ascontiguousarray(d[:, k]) for k in range(3)]
+        t = np.zeros(n, np.float32); prim = np.zeros(n, np.uint32); u = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+        inst = np.zeros(n, np.uint32)
+        lib().mpo_trace_rays_inst(self.h, *[_f32p(c) for c in cols], n, _f32p(t), _u32p(prim), _f32p(u), _f32p(v), _u32p(inst))
+        return t, prim, u, v, inst
 
     def tri_material(self) -> np.ndarray:
         return self._view(lib().mpo_bvh_tri_material(self.h), self.n_packets * 8 * 4, np.uint32).copy()

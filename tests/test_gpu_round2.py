@@ -275,3 +275,61 @@ def test_multi_device_behind_the_c_abi(oracle, teapot_oracle_bvh, n):
     assert np.array_equal(bits(img4.cpu().numpy()), bits(pf))
     with pytest.raises(mp.MinipathError):
         mp.MultiDeviceFrame([scenes[0], scenes[0]], cam, st).render()  # the same context twice
+
+
+def test_instanced_object(ctx, oracle, teapot_oracle_bvh):
+    """SURVEY 8 f3 second half (multi-object / instancing behind `trait Object`, scene/mod.rs:7-10): translated instances of one
+    TriangleBvh as the scene's object.  Build-defined (the reference has one object per Scene); the oracle states it operation by
+    operation; GPU == oracle bit for bit for hits (incl. which instance), frames (both traversals request the group walk), paths."""
+    import torch
+
+    base = mp.TriangleBvh.with_obj(TEAPOT, ctx)
+    tr = np.array([[0, 0, 0], [7.5, 0, -3], [-7.0, 0.5, -6], [0.25, 3.4, -1.0]], np.float32)
+    inst = mp.Instances(base, tr)
+    scene = mp.Scene(inst)
+    orc = oracle.Bvh.from_obj(TEAPOT)
+    orc.set_instances(tr)
+    i = inst.info()
+    assert i.triangle_count == 2256 and np.allclose(list(i.bbox_min), [-10, 0, -8]) and np.allclose(list(i.bbox_max)[:2], [10.92963, 6.55])
+    # hits
+    o, d = meshes.random_rays(30000, 4, np.array(list(i.bbox_min)), np.array(list(i.bbox_max)))
+    got = inst.intersect(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), full=True)
+    torch.cuda.synchronize()
+    t, prim, u, v, which = orc.trace_inst(o, d)
+    gp = got["prim"].cpu().numpy().view(np.uint32)
+    assert np.array_equal(gp, prim) and np.array_equal(got["instance"].cpu().numpy().view(np.uint32), which)
+    for k, e in (("t", t), ("u", u), ("v", v)):
+        assert np.array_equal(bits(got[k].cpu().numpy()), bits(e)), k
+    hit = prim != 0xFFFFFFFF
+    assert sorted(np.unique(which[hit]).tolist()) == [0, 1, 2, 3]
+    r = oracle.ray_new(o[hit][5], d[hit][5])
+    h = orc.intersect(r)
+    assert np.array_equal(bits(got["point"].cpu().numpy()[hit][5]), bits(np.array(list(h.point), np.float32)))  # world-space point
+    assert np.array_equal(bits(got["normal"].cpu().numpy()[hit][5]), bits(np.array(list(h.normal), np.float32)))
+    # frames: reference semantics and the path extension
+    import ctypes as C
+
+    oc = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(oc))
+    oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(0, 6, 22), oracle.vec3(0, 2, -2), oracle.vec3(0, 1, 0))
+    cam = mp.Camera.default().look_at((0, 6, 22), (0, 2, -2), (0, 1, 0))
+    res = (192, 128)
+    osmp = oracle.build_sampler(oc, *res)
+    of, _, _, _, _ = orc.render_image_mt(osmp, res[0], res[1], 5, 3, 32, 8)
+    for traversal in ("packets", "groups"):
+        a, seg = _render(scene, cam, mp.RenderSettings(32, 5, res, seed=3, traversal=traversal))
+        assert np.array_equal(bits(a), bits(of)), traversal
+        assert seg == res[0] * res[1] * 5
+    assert (of[..., 3] > 0).mean() > 0.15
+    pf, _, _, pseg = orc.render_image_paths_mt(osmp, res[0], res[1], 4, 3, 5, 32, 8)
+    b, gseg = _render(scene, cam, mp.RenderSettings(32, 4, res, seed=3, max_depth=5))
+    assert np.array_equal(bits(b), bits(pf)) and gseg == pseg
+    with pytest.raises(mp.MinipathError):
+        _render(scene, cam, mp.RenderSettings(32, 4, res, seed=3, max_depth=5, wavefront=True))
+    with pytest.raises(mp.MinipathError):
+        mp.Instances(inst, tr)  # instances of instances are not defined
+    # one identity instance == the plain object
+    one = mp.Scene(mp.Instances(base, [[0, 0, 0]]))
+    x, _ = _render(one, mp.Camera.teapot_view(), mp.RenderSettings(32, 6, (128, 96), seed=9))
+    y, _ = _render(mp.Scene(base), mp.Camera.teapot_view(), mp.RenderSettings(32, 6, (128, 96), seed=9))
+    assert np.array_equal(bits(x), bits(y))
