@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libminipath_hip.so")
+# MINIPATH_HIP_SO: experiment builds of the same library (kernel variants under measurement); default = the in-tree build
+SO_PATH = os.environ.get("MINIPATH_HIP_SO") or os.path.join(_HERE, "csrc", "libminipath_hip.so")
 
 MP_OK = 0
 MP_NO_PRIM = 0xFFFFFFFF

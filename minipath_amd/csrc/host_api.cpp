@@ -332,12 +332,18 @@ int upload_scene(mp_scene* s) {
         s->dev.boxes_ordered = ordered ? 1u : 0u;
     }
     // AoS copies for the scalar-unit fetch of the ray-packet traversal (same values, different order)
-    std::vector<float> nodes_aos(std::max<size_t>(ni, 1) * 64, 0.0f);
-    for (size_t n = 0; n < ni; n++)
+    // child record = {min.xyz, max.xyz, link, n}: n (record 0 only) = index of the node's last real child + 1 (the packet walk's
+    // loop bound; the builder packs real children first, imported trees may have null links in between, which are skipped)
+    std::vector<float> nodes_aos(std::max<size_t>(ni, 1) * 64 + 16, 0.0f);  // + tail padding: the child loop fetches one record ahead
+    for (size_t n = 0; n < ni; n++) {
+        uint32_t nchild = 0;
         for (int i = 0; i < 8; i++) {
             for (int k = 0; k < 6; k++) nodes_aos[n * 64 + i * 8 + k] = nodes[n * kNodeDwords + k * 8 + i];
             nodes_aos[n * 64 + i * 8 + 6] = nodes[n * kNodeDwords + 48 + i];
+            if (h.inner[n].link[i] != MP_LINK_NULL) nchild = static_cast<uint32_t>(i) + 1u;
         }
+        std::memcpy(&nodes_aos[n * 64 + 7], &nchild, 4);
+    }
     std::vector<float> tris_aos(np * 8 * kTriDwords + 4 * kTriDwords, 0.0f);  // + tail padding: the triangle loop prefetches up to two ahead
     std::vector<uint32_t> pkt_valid(np, 0);
     for (size_t p = 0; p < np; p++)

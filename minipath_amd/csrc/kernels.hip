@@ -589,12 +589,14 @@ struct PacketHit {
     uint32_t prim;
 };
 
-// The shared traversal stack is wave-uniform and lives in four VGPRs used as 64-entry arrays (entry k = lane k,
-// written with a lane-select, read with v_readlane and a scalar index): link, source slot (node*8+child, to re-derive
-// the entry distance) and the 64-bit mask of lanes that passed the slab test when the entry was pushed.
-// The pop-time cull `node_t1 > best.t` (:40) needs the ray's own entry distance t1: it can only fire for a lane
-// whose best.t shrank after the push, so while no lane accepted a hit since then (entry not "stale") the pushed
-// mask is the answer; otherwise t1 is recomputed from the child's box (same operations, same bits as at push time).
+// The shared traversal stack is wave-uniform and lives in four VGPRs used as 64-entry arrays (entry k = lane k, written with
+// v_writelane, read with v_readlane, both with a scalar index and both regardless of EXEC): link, source slot (node*8+child, to
+// re-derive the entry distance) and the 64-bit mask of lanes that passed the slab test when the entry was pushed.
+// The pop-time cull `node_t1 > best.t` (:40) needs the ray's own entry distance t1: it can only fire for a lane whose best.t
+// shrank after the push, so while no lane accepted a hit since then (entry not "stale") the pushed mask is the answer; otherwise
+// t1 is recomputed from the child's box (same operations, same bits as at push time).  Staleness needs no per-entry state: the
+// entries that predate the last change of any best.t are exactly those below a low-water mark of the stack pointer
+// (`stale_top` in trace_packet_impl: set to sp when a leaf changed a best.t, lowered by every pop).
 constexpr uint32_t kSrcRoot = 0xFFFFFFFFu;
 
 template <bool PATCH_NAN, int OCT>
@@ -604,71 +606,72 @@ __device__ __forceinline__ float slab_entry(float bnx, float bny, float bnz, flo
     return t1;
 }
 
-// Wave-uniform stack in registers: four VGPRs used as 64-entry arrays + a 64-bit stale mask in SGPRs.
+// Wave-uniform stack in registers: four VGPRs used as 64-entry arrays.
 struct RegStack {
     int link, src, mlo, mhi;
-    uint64_t stale;  // bit k: some lane's best.t changed after entry k was pushed
-    int lane;
-    __device__ __forceinline__ RegStack(float*, int lane_) : link(0), src(0), mlo(0), mhi(0), stale(0), lane(lane_) {}
+    __device__ __forceinline__ RegStack(float*, int) : link(0), src(0), mlo(0), mhi(0) {}
+    // v_writelane_b32 ignores EXEC: a push made while only the rays of the current node are enabled still lands in lane `sp`
+    // (gfx9 allows one SGPR operand per VALU instruction: the lane select goes through M0, which nothing else in these kernels uses)
     __device__ __forceinline__ void push(int sp, uint32_t l, uint32_t s, uint64_t m) {
-        const bool slot = lane == sp;
-        link = slot ? static_cast<int>(l) : link;
-        src = slot ? static_cast<int>(s) : src;
-        mlo = slot ? static_cast<int>(static_cast<uint32_t>(m)) : mlo;
-        mhi = slot ? static_cast<int>(static_cast<uint32_t>(m >> 32)) : mhi;
-        stale &= ~(1ull << sp);
+        asm volatile(
+            "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+            "v_writelane_b32 %0, %5, m0\n\tv_writelane_b32 %1, %6, m0\n\tv_writelane_b32 %2, %7, m0\n\tv_writelane_b32 %3, %8, m0"
+            : "+v"(link), "+v"(src), "+v"(mlo), "+v"(mhi)
+            : "s"(sp), "s"(l), "s"(s), "s"(static_cast<uint32_t>(m)), "s"(static_cast<uint32_t>(m >> 32))
+            : "m0");
     }
-    __device__ __forceinline__ void pop(int sp, uint32_t& l, uint32_t& s, uint64_t& m, bool& is_stale) const {
+    __device__ __forceinline__ void pop(int sp, uint32_t& l, uint32_t& s, uint64_t& m) const {
         l = static_cast<uint32_t>(__builtin_amdgcn_readlane(link, sp));
         s = static_cast<uint32_t>(__builtin_amdgcn_readlane(src, sp));
         m = static_cast<uint32_t>(__builtin_amdgcn_readlane(mlo, sp)) |
             (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(mhi, sp))) << 32);
-        is_stale = ((stale >> sp) & 1ull) != 0ull;
     }
-    __device__ __forceinline__ void all_stale() { stale = ~0ull; }
     __device__ __forceinline__ void sync(int) {}
 };
 
 // Trees deeper than 9 levels (7*depth+1 > 64) can in principle need more entries: those above 63 go to LDS (one uint4
-// {link, src, mask} + an epoch word per entry, written by lane 0, read back as a broadcast).  Real walks rarely get there
+// {link, src, mask} per entry, written by lane 0, read back as a broadcast).  Real walks rarely get there
 // (the 28-level atrium tree peaks at 16 entries per ray), so the register path stays the common one.
 struct HybridStack {
     RegStack reg;
     uint4* ent;
-    uint32_t* ep;
-    uint32_t epoch;
+    int lane;
     int nreg;  // entries kept in registers (<= 64; lowered only by the mp_ctx_set_option test knob)
-    __device__ __forceinline__ HybridStack(float* lds, int lane_, uint32_t cap, uint32_t nreg_)
-        : reg(nullptr, lane_), ent(reinterpret_cast<uint4*>(lds)), ep(nullptr), epoch(0), nreg(static_cast<int>(nreg_)) {
-        ep = reinterpret_cast<uint32_t*>(ent + (cap > nreg_ ? cap - nreg_ : 0u));
-    }
+    __device__ __forceinline__ HybridStack(float* lds, int lane_, uint32_t, uint32_t nreg_)
+        : reg(nullptr, lane_), ent(reinterpret_cast<uint4*>(lds)), lane(lane_), nreg(static_cast<int>(nreg_)) {}
     __device__ __forceinline__ void push(int sp, uint32_t l, uint32_t s, uint64_t m) {
         if (sp < nreg) {
             reg.push(sp, l, s, m);
-        } else if (reg.lane == 0) {
+        } else if (lane == 0) {
             ent[sp - nreg] = make_uint4(l, s, static_cast<uint32_t>(m), static_cast<uint32_t>(m >> 32));
-            ep[sp - nreg] = epoch;
         }
     }
-    __device__ __forceinline__ void pop(int sp, uint32_t& l, uint32_t& s, uint64_t& m, bool& is_stale) const {
+    __device__ __forceinline__ void pop(int sp, uint32_t& l, uint32_t& s, uint64_t& m) const {
         if (sp < nreg) {
-            reg.pop(sp, l, s, m, is_stale);
+            reg.pop(sp, l, s, m);
         } else {
             const uint4 e = ent[sp - nreg];
-            const uint32_t pe = ep[sp - nreg];
             l = __builtin_amdgcn_readfirstlane(e.x);
             s = __builtin_amdgcn_readfirstlane(e.y);
             m = __builtin_amdgcn_readfirstlane(e.z) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(e.w)) << 32);
-            is_stale = __builtin_amdgcn_readfirstlane(pe) != epoch;
         }
     }
-    __device__ __forceinline__ void all_stale() { reg.all_stale(); epoch++; }
     __device__ __forceinline__ void sync(int sp) { if (sp > nreg) wave_lds_sync(); }
 };
 
+__device__ __forceinline__ uint32_t uniform_u(float f) { return __builtin_amdgcn_readfirstlane(as_u(f)); }
+
 // MODE 1: every active ray has finite inverse directions (no 0*inf, so the NaN patches of aabb.rs:262-267 are dead code).
-// MODE 2: literal aabb.rs:254-284.  (A third variant that ordered each child's planes by a wave-uniform ray octant and dropped
-// the min/max was measured and rejected: +13 VGPRs, no gain -- profiles/r01_notes.md.)
+// MODE 2: literal aabb.rs:254-284.
+//
+// The walk is fed by the scalar unit (wave-uniform node / triangle records through s_load), and measured on MI355X it is the
+// SCALAR ALU, one per CU, that saturates first (profiles/r02_notes.md: an extra SALU instruction per triangle costs 4x what an
+// extra VALU instruction costs).  So per-ray predicates that used to be combined as lane masks with s_and / s_andn2 / s_cmp are
+// folded into the vector domain: the rays a popped entry is NOT live for are disabled through two per-lane operands -- `lim`
+// (best.t, or -1 for a disabled ray: no slab interval and no hit distance passes) and `thr` (the early-out threshold -2^-40, or
+// +inf: a disabled ray is always "surely rejected") -- so every ballot below is already the masked result and "no ray left" is a
+// branch on VCC; det's magnitude guard is a v_cndmask, the three sign tests one minNum chain; loops are single-exit pair loops
+// with a scalar countdown; pushes are v_writelane; staleness is a low-water mark instead of a 64-bit mask.
 template <int MODE, int OCT, class Stack>
 __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
     constexpr bool PATCH_NAN = MODE == 2;
@@ -681,36 +684,50 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
     st.push(0, sc.root, kSrcRoot, __ballot(active));
     st.sync(1);
     int sp = 1;
+    int stale_top = 0;  // entries [0, stale_top) were pushed before some ray's best.t last changed
     while (sp > 0) {
         sp--;
         uint32_t link, src;
-        uint64_t pm;
-        bool is_stale;
-        st.pop(sp, link, src, pm, is_stale);
-        uint64_t onm = pm;  // rays this entry is still live for
-        if (is_stale && src != kSrcRoot) {  // :40-44, per ray
+        uint64_t onm;  // rays this entry is still live for
+        st.pop(sp, link, src, onm);
+        if (sp < stale_top) {  // :40-44, per ray (the root is popped first, before anything can be stale)
+            stale_top = sp;
             kfp bx = nodes + static_cast<size_t>(src) * 8;
             const float node_t1 = slab_entry<PATCH_NAN, OCT>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], r);
             onm &= ~mask_gt(node_t1, best_t);
         }
         if (onm == 0) continue;
+        const bool on = __builtin_amdgcn_inverse_ballot_w64(onm);
+        float lim = on ? best_t : -1.0f;          // slab limit / hit-distance bound: nothing passes for a disabled ray
         if ((link & 7u) == 0u) {
-            // InnerNode::intersect :149-162, children ascending
+            // InnerNode::intersect :149-162, children ascending.  Child record = {min.xyz, max.xyz, link, n}: n (record 0 only)
+            // = index of the node's last real child + 1.  Two SGPR sets alternate: B is fetched while A is tested.
             const uint32_t node = link >> 3;
             kfp nd = nodes + static_cast<size_t>(node) * 64;
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const uint32_t child = __builtin_amdgcn_readfirstlane(as_u(nd[c * 8 + 6]));
-                if (child == MP_LINK_NULL) continue;
+            float a0 = nd[0], a1 = nd[1], a2 = nd[2], a3 = nd[3], a4 = nd[4], a5 = nd[5], a6 = nd[6];
+            const uint32_t nchild = uniform_u(nd[7]);
+            uint32_t slot = node * 8u;
+            auto child = [&](const float b0, const float b1, const float b2, const float b3, const float b4, const float b5,
+                             const float blink, const uint32_t cslot) {
+                const uint32_t cl = uniform_u(blink);
+                if (cl == MP_LINK_NULL) return;  // Null links are skipped at pop in the reference (:49)
                 float t1, t2;
-                slab<PATCH_NAN, OCT>(nd[c * 8 + 0], nd[c * 8 + 1], nd[c * 8 + 2], nd[c * 8 + 3], nd[c * 8 + 4], nd[c * 8 + 5], r, best_t,
-                                t1, t2);
-                const uint64_t okm = onm & mask_le(t1, t2);
+                slab<PATCH_NAN, OCT>(b0, b1, b2, b3, b4, b5, r, lim, t1, t2);
+                const uint64_t okm = __ballot(t1 <= t2);
                 if (okm != 0) {
-                    st.push(sp, child, node * 8u + c, okm);
+                    st.push(sp, cl, cslot, okm);
                     sp++;
                 }
+            };
+            for (uint32_t p = nchild >> 1; p > 0; p--) {
+                const float b0 = nd[8], b1 = nd[9], b2 = nd[10], b3 = nd[11], b4 = nd[12], b5 = nd[13], b6 = nd[14];
+                child(a0, a1, a2, a3, a4, a5, a6, slot);
+                a0 = nd[16]; a1 = nd[17]; a2 = nd[18]; a3 = nd[19]; a4 = nd[20]; a5 = nd[21]; a6 = nd[22];
+                child(b0, b1, b2, b3, b4, b5, b6, slot + 1u);
+                slot += 2u;
+                nd += 16;
             }
+            if (nchild & 1u) child(a0, a1, a2, a3, a4, a5, a6, slot);
             st.sync(sp);
         } else {
             // intersect_triangles :104-140 ; every lane walks the leaf's triangles in (packet, lane) order with a
@@ -718,8 +735,8 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
             const uint32_t first = link >> 3, count = link & 7u;
             const uint32_t n_real = (count - 1u) * 8u + __builtin_amdgcn_readfirstlane(nvalid[first + count - 1u]);
             kfp tp = tris + static_cast<size_t>(first) * (8 * kTriDwords);
+            const float thr = on ? -kTiny : INFINITY;  // early-out threshold: a disabled ray is always "surely rejected"
             uint64_t changed = 0;  // lanes that accepted a hit in this leaf
-            // One triangle test; all predicates are lane masks combined with `&` (no short-circuit control flow).
             auto test = [&](const float v0x, const float v0y, const float v0z, const float e1x, const float e1y, const float e1z,
                             const float e2x, const float e2y, const float e2z, const uint32_t tri) {
                 // triangle.rs:183-217
@@ -727,41 +744,45 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 const float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
                 const float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
                 const float un = fma_dot(sx, sy, sz, hx, hy, hz);
+                // Exact early-outs.  A numerator whose sign differs from det's, with |num| >= 2^-40 and |det| <= 2^40, gives a
+                // non-zero negative quotient fl(fl(1/det) * num) (no underflow to -0, which would pass `>= 0`): u >= 0 (v >= 0,
+                // t >= 0) cannot hold.  x = num with its sign flipped by det's (or +1 where |det| is too large to tell):
+                // "surely negative" is the single ordered compare x <= -2^-40; NaN never rejects.
                 const uint32_t det_sign = as_u(det) & 0x80000000u;
-                const uint64_t det_ok = mask_le(fabsf(det), kHuge);
-                const uint64_t rej_u = surely_negative_mask(un, det_sign, det_ok);  // u >= 0 cannot hold
-                if ((onm & ~rej_u) == 0) return;
+                const bool det_ok = fabsf(det) <= kHuge;
+                const float xu = det_ok ? as_f(as_u(un) ^ det_sign) : 1.0f;
+                if (__ballot(!(xu <= thr)) == 0) return;  // no live ray can have u >= 0
                 const float qx = fms(sy, e1z, sz * e1y), qy = fms(sz, e1x, sx * e1z), qz = fms(sx, e1y, sy * e1x);
                 const float vn = fma_dot(r.dx, r.dy, r.dz, qx, qy, qz);
                 const float tn = fma_dot(e2x, e2y, e2z, qx, qy, qz);
-                const uint64_t rej_vt = surely_negative_mask(vn, det_sign, det_ok) | surely_negative_mask(tn, det_sign, det_ok);  // v >= 0 / t >= 0 cannot hold
-                if ((onm & ~rej_u & ~rej_vt) == 0) return;
+                const float xv = det_ok ? as_f(as_u(vn) ^ det_sign) : 1.0f, xt = det_ok ? as_f(as_u(tn) ^ det_sign) : 1.0f;
+                // minNum drops NaN operands, so the minimum is <= the threshold iff one of the three ordered compares holds
+                if (__ballot(!(fminf(fminf(xu, xv), xt) <= thr)) == 0) return;
                 const float inv_det = 1.0f / det;
                 const float u = inv_det * un, v = inv_det * vn, t = inv_det * tn;
                 // mask & t>=0 & t<=max_t (:125), strict `<` vs the leaf best, then vs the global best (:129,:59):
-                // equivalent to a running strict `<` against best.t (best.t never exceeds max_t)
-                const uint64_t accm = onm & mask_ge(u, 0.0f) & mask_ge(v, 0.0f) & mask_le(u + v, 1.0f) & mask_ge(t, 0.0f) & mask_lt(t, best_t);
-                const bool acc = __builtin_amdgcn_inverse_ballot_w64(accm);
+                // equivalent to a running strict `<` against best.t (best.t never exceeds max_t); lim == best.t for live rays
+                const bool acc = (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) & (t >= 0.0f) & (t < lim);
                 best_t = acc ? t : best_t;
+                lim = acc ? t : lim;
                 bu = acc ? u : bu;
                 bv = acc ? v : bv;
                 bprim = acc ? tri : bprim;
-                changed |= accm;
+                changed |= __ballot(acc);
             };
             // two register sets (A, B) alternate: B is fetched while A is tested and vice versa (the array has tail padding)
             float a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3], a4 = tp[4], a5 = tp[5], a6 = tp[6], a7 = tp[7], a8 = tp[8];
-            uint32_t i = 0;
-            const uint32_t base = first * 8u;
-            for (;;) {
+            uint32_t tri = first * 8u;
+            for (uint32_t p = n_real >> 1; p > 0; p--) {
                 const float b0 = tp[9], b1 = tp[10], b2 = tp[11], b3 = tp[12], b4 = tp[13], b5 = tp[14], b6 = tp[15], b7 = tp[16], b8 = tp[17];
-                test(a0, a1, a2, a3, a4, a5, a6, a7, a8, base + i);
-                if (++i == n_real) break;
+                test(a0, a1, a2, a3, a4, a5, a6, a7, a8, tri);
                 a0 = tp[18]; a1 = tp[19]; a2 = tp[20]; a3 = tp[21]; a4 = tp[22]; a5 = tp[23]; a6 = tp[24]; a7 = tp[25]; a8 = tp[26];
-                test(b0, b1, b2, b3, b4, b5, b6, b7, b8, base + i);
-                if (++i == n_real) break;
+                test(b0, b1, b2, b3, b4, b5, b6, b7, b8, tri + 1u);
+                tri += 2u;
                 tp += 2 * kTriDwords;
             }
-            if (changed != 0) st.all_stale();  // every entry still on the stack predates this change
+            if (n_real & 1u) test(a0, a1, a2, a3, a4, a5, a6, a7, a8, tri);
+            if (changed != 0) stale_top = sp;  // every entry still on the stack predates this change
         }
     }
     hit.t = best_t; hit.u = bu; hit.v = bv; hit.prim = bprim;
