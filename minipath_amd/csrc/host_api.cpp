@@ -332,24 +332,11 @@ int upload_scene(mp_scene* s) {
         s->dev.boxes_ordered = ordered ? 1u : 0u;
     }
     // AoS copies for the scalar-unit fetch of the ray-packet traversal (same values, different order)
-    // child record = {min.xyz, max.xyz, link, n}: n (record 0 only) = index of the node's last real child + 1 (the packet walk's
-    // loop bound; the builder packs real children first, imported trees may have null links in between, which are skipped)
-    std::vector<float> nodes_aos(std::max<size_t>(ni, 1) * 64 + 16, 0.0f);  // + tail padding: the child loop fetches one record ahead
-    for (size_t n = 0; n < ni; n++) {
-        uint32_t nchild = 0;
-        for (int i = 0; i < 8; i++) {
-            for (int k = 0; k < 6; k++) nodes_aos[n * 64 + i * 8 + k] = nodes[n * kNodeDwords + k * 8 + i];
-            nodes_aos[n * 64 + i * 8 + 6] = nodes[n * kNodeDwords + 48 + i];
-            if (h.inner[n].link[i] != MP_LINK_NULL) nchild = static_cast<uint32_t>(i) + 1u;
-        }
-        std::memcpy(&nodes_aos[n * 64 + 7], &nchild, 4);
-    }
-    std::vector<float> tris_aos(np * 8 * kTriDwords + 4 * kTriDwords, 0.0f);  // + tail padding: the triangle loop prefetches up to two ahead
+    // real (unpadded) triangles per packet: padding lanes are all-zero quantised triangles with default shading, at the tail of a
+    // leaf's last packet
     std::vector<uint32_t> pkt_valid(np, 0);
     for (size_t p = 0; p < np; p++)
         for (int i = 0; i < 8; i++) {
-            for (int k = 0; k < 9; k++) tris_aos[(p * 8 + i) * kTriDwords + k] = tris[p * kPacketDwords + k * 8 + i];
-            // padding lanes are all-zero quantised triangles with default shading, at the tail of a leaf's last packet
             bool pad = true;
             for (int a = 0; a < 3 && pad; a++)
                 for (int k = 0; k < 3; k++)
@@ -358,6 +345,32 @@ int upload_scene(mp_scene* s) {
             pad = pad && sh.vi[0] == 0 && sh.vi[1] == 0 && sh.vi[2] == 0 && sh.flat == 0;
             if (!pad) pkt_valid[p] = static_cast<uint32_t>(i + 1);
         }
+    if (np >= (1u << 26) - 1u || ni >= (1u << 26)) return fail(MP_ERR_UNSUPPORTED, "scene too large for the device link format (2^26-2 packets)");
+    // device link (mp_internal.h): inner = index << 6 ; leaf = first packet << 6 | real triangles ; null unchanged
+    auto dlink = [&](uint32_t l) -> uint32_t {
+        if (l == MP_LINK_NULL) return l;
+        const uint32_t idx = l >> 3, cnt = l & 7u;
+        if (cnt == 0u) return idx << 6;
+        const uint32_t n_real = (cnt - 1u) * 8u + pkt_valid[idx + cnt - 1u];
+        return (idx << 6) | std::max<uint32_t>(n_real, 1u);  // a leaf of padding only (imported arrays) still tests one, never-hit, triangle
+    };
+    // child record = {min.xyz, max.xyz, dlink, n}: n (record 0 only) = index of the node's last real child + 1 (the packet walk's
+    // loop bound; the builder packs real children first, imported trees may have null links in between, which are skipped)
+    std::vector<float> nodes_aos(std::max<size_t>(ni, 1) * 64 + 16, 0.0f);  // + tail padding: the child loop fetches one record ahead
+    for (size_t n = 0; n < ni; n++) {
+        uint32_t nchild = 0;
+        for (int i = 0; i < 8; i++) {
+            for (int k = 0; k < 6; k++) nodes_aos[n * 64 + i * 8 + k] = nodes[n * kNodeDwords + k * 8 + i];
+            const uint32_t dl = dlink(h.inner[n].link[i]);
+            std::memcpy(&nodes_aos[n * 64 + i * 8 + 6], &dl, 4);
+            if (h.inner[n].link[i] != MP_LINK_NULL) nchild = static_cast<uint32_t>(i) + 1u;
+        }
+        std::memcpy(&nodes_aos[n * 64 + 7], &nchild, 4);
+    }
+    std::vector<float> tris_aos(np * 8 * kTriDwords + 4 * kTriDwords, 0.0f);  // + tail padding: the triangle loop prefetches up to two ahead
+    for (size_t p = 0; p < np; p++)
+        for (int i = 0; i < 8; i++)
+            for (int k = 0; k < 9; k++) tris_aos[(p * 8 + i) * kTriDwords + k] = tris[p * kPacketDwords + k * 8 + i];
     auto up = [&](void** dst, const void* src, size_t bytes) -> int {
         bytes = std::max<size_t>(bytes, 16);
         MP_HIP(hipMalloc(dst, bytes));
@@ -388,7 +401,7 @@ int upload_scene(mp_scene* s) {
     s->dev.nodes_aos = static_cast<const float*>(s->d_nodes_aos);
     s->dev.tris_aos = static_cast<const float*>(s->d_tris_aos);
     s->dev.pkt_valid = static_cast<const uint32_t*>(s->d_pkt_valid);
-    s->dev.root = h.root;
+    s->dev.root = dlink(h.root);
     s->dev.inner_count = static_cast<uint32_t>(ni);
     s->dev.packet_count = static_cast<uint32_t>(np);
     // Exact bound of the traversal stack: a node pushes at most its real (non-null) children in ascending order and pops

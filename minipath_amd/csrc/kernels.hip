@@ -231,10 +231,10 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
             float node_t1 = as_f(e.y);
             if (!(node_t1 > best_t)) {  // :40-44
                 uint32_t link = e.x;
-                if ((link & 7u) == 0u) {
+                if ((link & 63u) == 0u) {  // device link (mp_internal.h): inner = index << 6
                     // InnerNode::intersect :149-162 ; lane li = child li.  Child boxes are stored decompressed
                     // (SURVEY A.4 box chain evaluated once on the host), so the slab test starts directly.
-                    const float4* cp = nodes4 + (static_cast<size_t>(link >> 3) * 8 + li) * 2;
+                    const float4* cp = nodes4 + (static_cast<size_t>(link >> 6) * 8 + li) * 2;
                     const float4 c0 = cp[0], c1 = cp[1];  // {min.xyz, max.x} {max.yz, link, -}
                     const uint32_t child = as_u(c1.z);
                     // aabb.rs:254-284
@@ -251,8 +251,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
                     if (ok) stack[sp + __popc(m & lanes_below)] = make_uint2(child, as_u(t1));  // ascending lane :161
                     sp += __popc(m);
                 } else {
-                    pk = link >> 3;  // Leaf :56-62
-                    pk_end = pk + (link & 7u);
+                    pk = link >> 6;  // Leaf :56-62 ; device link = first packet << 6 | real triangles
+                    pk_end = pk + (((link & 63u) + 7u) >> 3);
                 }
             }
         }
@@ -677,7 +677,6 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
     constexpr bool PATCH_NAN = MODE == 2;
     kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
     kfp tris = (kfp)(uintptr_t)sc.tris_aos;
-    kup nvalid = (kup)(uintptr_t)sc.pkt_valid;
     float best_t = FLT_MAX, bu = 0.0f, bv = 0.0f;  // best (:34-37)
     uint32_t bprim = kNoPrim;
     // entry 0 = root (:28-32), t1 = -inf: never culled
@@ -699,10 +698,10 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
         if (onm == 0) continue;
         const bool on = __builtin_amdgcn_inverse_ballot_w64(onm);
         float lim = on ? best_t : -1.0f;          // slab limit / hit-distance bound: nothing passes for a disabled ray
-        if ((link & 7u) == 0u) {
+        if ((link & 63u) == 0u) {  // device link (mp_internal.h): inner = index << 6, leaf = first packet << 6 | real triangles
             // InnerNode::intersect :149-162, children ascending.  Child record = {min.xyz, max.xyz, link, n}: n (record 0 only)
             // = index of the node's last real child + 1.  Two SGPR sets alternate: B is fetched while A is tested.
-            const uint32_t node = link >> 3;
+            const uint32_t node = link >> 6;
             kfp nd = nodes + static_cast<size_t>(node) * 64;
             float a0 = nd[0], a1 = nd[1], a2 = nd[2], a3 = nd[3], a4 = nd[4], a5 = nd[5], a6 = nd[6];
             const uint32_t nchild = uniform_u(nd[7]);
@@ -732,8 +731,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
         } else {
             // intersect_triangles :104-140 ; every lane walks the leaf's triangles in (packet, lane) order with a
             // strict `<`.  Padding (only at the tail of the last packet) can never be accepted and is not visited.
-            const uint32_t first = link >> 3, count = link & 7u;
-            const uint32_t n_real = (count - 1u) * 8u + __builtin_amdgcn_readfirstlane(nvalid[first + count - 1u]);
+            const uint32_t first = link >> 6, n_real = link & 63u;  // the count travels in the link: no dependent load before the first triangle
             kfp tp = tris + static_cast<size_t>(first) * (8 * kTriDwords);
             const float thr = on ? -kTiny : INFINITY;  // early-out threshold: a disabled ray is always "surely rejected"
             uint64_t changed = 0;  // lanes that accepted a hit in this leaf

@@ -61,12 +61,16 @@ int load_obj(const char* path, std::vector<float>& pos, std::vector<float>& nrm,
 int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err);
 
 // ---- device scene ("traversal format") -------------------------------------------------------
-// nodes_aos : inner_count x 8 children x 8 dwords {minx,miny,minz,maxx,maxy,maxz,link,0}: absolute decompressed child boxes.
+// nodes_aos : inner_count x 8 children x 8 dwords {minx,miny,minz,maxx,maxy,maxz,dlink,n}: absolute decompressed child boxes;
+//             n (record 0 only) = index of the node's last real child + 1.
+// dlink     : device-private link (the reference's CompressedNodeLink idx<<3|count, mod.rs:57-114, re-encoded so that a leaf needs
+//             no side lookup): inner = node index << 6 ; leaf = first packet << 6 | real (unpadded) triangles of the leaf (1..56) ;
+//             null = MP_LINK_NULL unchanged (checked before decoding; scenes are limited to 2^26-2 packets).
 // tris_aos  : packet_count x 8 triangles x kTriDwords (9) dwords {v0.xyz,e1.xyz,e2.xyz}: decompressed v0 and the edges e1=v1-v0,
 //             e2=v2-v0 of triangle.rs:195-196 (+ 3 records of tail padding: the packet walk fetches two triangles ahead).
 //             The packet walk reads both through the scalar unit (wave-uniform), the 8-lane-group walk with per-lane vector loads
 //             (lane i = child i / triangle i).
-// pkt_valid : real (unpadded) triangles of each packet.
+// pkt_valid : real (unpadded) triangles of each packet (host staging for dlink; kept on the device for diagnostics).
 // shade     : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) material(u32 bits) pad.  48 B per triangle slot.
 // vidx/vtex : for the full HitRecord (texture_coords).
 struct DevScene {
@@ -83,7 +87,7 @@ struct DevScene {
     float sky = 1.0f;                  // ... and the sky radiance
     uint32_t inst_count = 0;           // build-defined instanced Object: translations (device, xyz per instance); 0 = plain BVH
     const float* inst_t = nullptr;
-    uint32_t root = MP_LINK_NULL;
+    uint32_t root = MP_LINK_NULL;    // dlink of the root
     uint32_t inner_count = 0;
     uint32_t packet_count = 0;
     uint32_t stack_cap = 1;          // exact traversal-stack bound (upload_scene)
