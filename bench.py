@@ -31,7 +31,8 @@ segment); `achieved` / `frac` follow that definition and are MODELLED bytes over
 The fused kernels keep ray state in registers, so their real HBM traffic is far smaller: `traffic` (bytes per launch) and
 `hbm_measured_gbs` come from rocprofv3 PMC counters of the same workload (profiles/r02_counters.json; FETCH_SIZE x 2 +
 WRITE_SIZE, the guide's gfx950 correction), and the actual limiter is reported as `valu_issue_frac` = SQ_INSTS_VALU x 2 cycles
-/ (SIMDs x 2.4 GHz x kernel time) with the live kernel time of this run.
+/ (SIMDs x 2.4 GHz x kernel time) and `salu_issue_frac` = SQ_INSTS_SALU / (CUs x 2.4 GHz x kernel time), both with the live
+kernel time of this run.
 """
 import argparse
 import json
@@ -272,6 +273,8 @@ def main():
                 r["valu_issue_frac"] = c["SQ_INSTS_VALU"] * VALU_CYCLES / (simds * SHADER_CLOCK_HZ * k_s)
                 if c.get("valu_lane_utilisation"):
                     r["valu_lane_utilisation"] = c["valu_lane_utilisation"]
+                if c.get("SQ_INSTS_SALU"):  # one scalar ALU per CU, one instruction per cycle
+                    r["salu_issue_frac"] = c["SQ_INSTS_SALU"] / (cu_count * SHADER_CLOCK_HZ * k_s)
             r["counters_from"] = c.get("source", "profiles/r02_counters.json")
         return r
 
