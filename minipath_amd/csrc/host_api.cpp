@@ -154,7 +154,21 @@ struct mp_scene {
     void* d_nodes_aos = nullptr;
     void* d_tris_aos = nullptr;
     void* d_pkt_valid = nullptr;
-    void* d_materials = nullptr;
+    // material table of the path extension: shared by reference with the instanced scenes made from this scene (each keeps the
+    // table it was created with alive; mp_scene_set_materials gives a scene a new table of its own)
+    struct DevTable {
+        void* d = nullptr;
+        int device = 0;
+        ~DevTable() {
+            if (!d) return;
+            int prev = -1;
+            (void)hipGetDevice(&prev);
+            if (prev != device) (void)hipSetDevice(device);
+            (void)hipFree(d);
+            if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+        }
+    };
+    std::shared_ptr<DevTable> mat_table;
     void* d_inst = nullptr;               // mp_scene_instances: translations
     const mp_scene* inst_of = nullptr;    // ... of this object, whose device arrays this scene borrows
     std::vector<float> inst_t;
@@ -385,9 +399,14 @@ int upload_scene(mp_scene* s) {
     if ((rc = up(&s->d_nodes_aos, nodes_aos.data(), nodes_aos.size() * 4))) return rc;
     if ((rc = up(&s->d_tris_aos, tris_aos.data(), tris_aos.size() * 4))) return rc;
     if ((rc = up(&s->d_pkt_valid, pkt_valid.data(), pkt_valid.size() * 4))) return rc;
-    if ((rc = up(&s->d_materials, s->materials.data(), s->materials.size() * sizeof(mp_material)))) return rc;
-    MP_HIP(hipMemcpy(s->d_materials, s->materials.data(), s->materials.size() * sizeof(mp_material), hipMemcpyHostToDevice));
-    s->dev.materials = static_cast<const float*>(s->d_materials);
+    {
+        auto tb = std::make_shared<mp_scene::DevTable>();
+        tb->device = s->ctx->device;
+        if ((rc = up(&tb->d, s->materials.data(), s->materials.size() * sizeof(mp_material)))) return rc;
+        MP_HIP(hipMemcpy(tb->d, s->materials.data(), s->materials.size() * sizeof(mp_material), hipMemcpyHostToDevice));
+        s->mat_table = std::move(tb);
+    }
+    s->dev.materials = static_cast<const float*>(s->mat_table->d);
     s->dev.sky = s->sky;
     MP_HIP(hipMemcpy(s->d_nodes_aos, nodes_aos.data(), nodes_aos.size() * 4, hipMemcpyHostToDevice));
     if (!tris_aos.empty()) MP_HIP(hipMemcpy(s->d_tris_aos, tris_aos.data(), tris_aos.size() * 4, hipMemcpyHostToDevice));
@@ -723,7 +742,7 @@ int mp_scene_instances(mp_ctx* ctx, const mp_scene* object, const float* transla
     s->sky = object->sky;
     s->material_count = object->material_count;
     s->dev = object->dev;
-    s->d_materials = object->d_materials;
+    s->mat_table = object->mat_table;  // a snapshot: a later mp_scene_set_materials on `object` does not reach this scene
     s->dev.inst_count = n;
     if (ctx) {
         DeviceGuard g(ctx->device);
@@ -745,16 +764,14 @@ int mp_scene_set_materials(mp_scene* scene, const mp_material* table, uint32_t n
     if (n < scene->material_count) return fail(MP_ERR_INVALID, "material table shorter than the scene's material_count");
     scene->materials.assign(table, table + n);
     scene->sky = sky_radiance;
-    if (scene->ctx) {  // re-upload the table; renders already enqueued keep the old one alive until the device is idle
+    if (scene->ctx) {  // a new table for this scene; instanced scenes made earlier keep the one they were created with
         DeviceGuard g(scene->ctx->device);
-        void* d_new = nullptr;
-        MP_HIP(hipMalloc(&d_new, std::max<size_t>(16, n * sizeof(mp_material))));
-        hipError_t e = hipMemcpy(d_new, scene->materials.data(), n * sizeof(mp_material), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(d_new); return hip_fail(e, "hipMemcpy(materials)"); }
-        if (scene->d_materials && !(scene->inst_of && scene->d_materials == scene->inst_of->d_materials))
-            (void)hipFree(scene->d_materials);  // hipFree waits for the device
-        scene->d_materials = d_new;
-        scene->dev.materials = static_cast<const float*>(d_new);
+        auto tb = std::make_shared<mp_scene::DevTable>();
+        tb->device = scene->ctx->device;
+        MP_HIP(hipMalloc(&tb->d, std::max<size_t>(16, n * sizeof(mp_material))));
+        MP_HIP(hipMemcpy(tb->d, scene->materials.data(), n * sizeof(mp_material), hipMemcpyHostToDevice));
+        scene->mat_table = std::move(tb);  // the old table is freed when its last holder lets go (hipFree waits for the device)
+        scene->dev.materials = static_cast<const float*>(scene->mat_table->d);
         scene->dev.sky = sky_radiance;
     }
     return MP_OK;
@@ -785,14 +802,13 @@ void mp_scene_destroy(mp_scene* s) {
         if (s->ctx) {
             DeviceGuard g(s->ctx->device);
             if (s->d_inst) (void)hipFree(s->d_inst);
-            if (s->d_materials && s->d_materials != s->inst_of->d_materials) (void)hipFree(s->d_materials);
         }
         delete s;
         return;
     }
     if (s->ctx) {
         DeviceGuard g(s->ctx->device);
-        for (void* p : {s->d_shade, s->d_vidx, s->d_vtex, s->d_nodes_aos, s->d_tris_aos, s->d_pkt_valid, s->d_materials})
+        for (void* p : {s->d_shade, s->d_vidx, s->d_vtex, s->d_nodes_aos, s->d_tris_aos, s->d_pkt_valid})
             if (p) (void)hipFree(p);
     }
     delete s;

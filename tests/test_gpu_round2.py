@@ -333,3 +333,39 @@ def test_instanced_object(ctx, oracle, teapot_oracle_bvh):
     x, _ = _render(one, mp.Camera.teapot_view(), mp.RenderSettings(32, 6, (128, 96), seed=9))
     y, _ = _render(mp.Scene(base), mp.Camera.teapot_view(), mp.RenderSettings(32, 6, (128, 96), seed=9))
     assert np.array_equal(bits(x), bits(y))
+
+
+def test_instances_keep_the_material_table_they_were_made_with(ctx, oracle):
+    """Regression (found by tools/fuzz_gpu.py): an instanced scene shares its object's material table by reference; a later
+    mp_scene_set_materials on the object gives the OBJECT a new table and must neither free the old one under the instanced scene
+    nor be freed twice when the two are destroyed."""
+    import gc
+
+    pos, nrm, tex, tri = meshes.make("soup_300")
+    mat = (np.arange(tri.shape[0]) % 2).astype(np.uint32)
+    base = mp.TriangleBvh.build(pos, nrm, tex, tri, ctx, tri_material=mat)
+    orc = oracle.Bvh.build(pos, nrm, tex, tri, tri_material=mat)
+    cam = mp.Camera.default().look_at((0, 0, 9), (0, 0, 0), (0, 1, 0))
+    import ctypes as C
+
+    oc = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(oc))
+    oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(0, 0, 9), oracle.vec3(0, 0, 0), oracle.vec3(0, 1, 0))
+    osmp = oracle.build_sampler(oc, 64, 48)
+    st = mp.RenderSettings(16, 4, (64, 48), seed=2, max_depth=3)
+    t1, t2 = [(0.9, 0.0), (0.1, 3.0)], [(0.3, 1.0), (0.8, 0.0)]
+    tr = np.array([[0, 0, 0], [2.5, 0.5, 0]], np.float32)
+    base.set_materials(t1, 0.0)
+    inst = mp.Instances(base, tr)           # made with table t1
+    base.set_materials(t2, 1.0)             # the object moves on; the instanced scene must still show t1
+    orc.set_instances(tr); orc.set_materials(t1, 0.0)
+    of, _, _, _ = orc.render_image_paths_mt(osmp, 64, 48, 4, 2, 3, 16, 8)
+    a, _ = _render(mp.Scene(inst), cam, st)
+    assert np.array_equal(bits(a), bits(of))
+    orc.set_instances(np.zeros((0, 3), np.float32)); orc.set_materials(t2, 1.0)
+    of2, _, _, _ = orc.render_image_paths_mt(osmp, 64, 48, 4, 2, 3, 16, 8)
+    b, _ = _render(mp.Scene(base), cam, st)
+    assert np.array_equal(bits(b), bits(of2))
+    inst.close(); base.set_materials(t1, 0.5); del inst; gc.collect()
+    c, _ = _render(mp.Scene(base), cam, st)   # any double free above would surface here as a sticky HIP error
+    assert c.shape == b.shape

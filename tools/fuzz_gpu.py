@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the GPU render paths against the oracle: random small scenes, cameras (incl. axis-aligned views that
 produce zero direction components), resolutions, tile sizes, sample counts, kernels (packets / groups / fused paths / staged paths),
-work-unit sizes, progressive splits.  Every frame must match the oracle bit for bit.  usage: fuzz_gpu.py [cases] [seed]"""
+work-unit sizes, progressive splits, material tables and sky radiance, instanced objects, the chunked accumulation rule.  Every
+frame must match the oracle bit for bit.  usage: fuzz_gpu.py [cases] [seed]"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,7 +20,8 @@ def run(cases, seed, ctx=None):
     scenes = {}
     for name in ("soup_300", "grid_40", "sphere_24", "flat_plane", "soup_5000"):
         pos, nrm, tex, tri = meshes.make(name)
-        scenes[name] = (mp.Scene(mp.TriangleBvh.build(pos, nrm, tex, tri, ctx)), po.Bvh.build(pos, nrm, tex, tri))
+        mat = (np.arange(tri.shape[0]) * 7 % 3).astype(np.uint32)  # three materials, interleaved
+        scenes[name] = (mp.Scene(mp.TriangleBvh.build(pos, nrm, tex, tri, ctx, tri_material=mat)), po.Bvh.build(pos, nrm, tex, tri, tri_material=mat))
     bad = 0
     for case in range(cases):
         if case and case % 500 == 0:
@@ -44,22 +46,39 @@ def run(cases, seed, ctx=None):
         s_opt = int(rng.choice([0, 0, 1, 4, 8, 16, 32, 64]))
         ctx.set_option("packet_samples_in_flight", s_opt)
         ctx.set_option("packet_stack_registers", int(rng.choice([64, 64, 3, 9])))
-        st = mp.RenderSettings(ts, spp, (w, h), seed=seed, traversal="groups" if mode == "groups" else "packets", max_depth=depth, wavefront=(mode == "staged"))
-        fr = mp.FrameRenderer(scene, cam, st)
-        if rng.random() < 0.4 and spp > 1:   # progressive split
-            cut = int(rng.integers(1, spp)); nxt = fr.render_pass(0, cut); fr.render_pass(nxt)
+        chunked = bool(rng.random() < 0.25)
+        if chunked:
+            spp = int(rng.choice([spp, 300, 513]))
+        table = [(float(rng.uniform(0.1, 0.95)), float(rng.choice([0.0, 0.0, 2.5]))) for _ in range(3)]
+        sky = float(rng.choice([1.0, 0.0, 0.4]))
+        scene.object.set_materials(table, sky); ob.set_materials(table, sky)
+        use = scene
+        if mode != "staged" and rng.random() < 0.2:   # instanced object: 2-4 translated copies
+            tr = (rng.normal(size=(int(rng.integers(2, 5)), 3)) * 3.0).astype(np.float32)
+            use = mp.Scene(mp.Instances(scene.object, tr)); ob.set_instances(tr)
         else:
-            fr.render()
+            ob.set_instances(np.zeros((0, 3), np.float32))
+        po.lib().mpo_set_chunked_sum(1 if chunked else 0)
+        st = mp.RenderSettings(ts, spp, (w, h), seed=seed, traversal="groups" if mode == "groups" else "packets", max_depth=depth, wavefront=(mode == "staged"),
+                               chunked_sum=chunked)
+        fr = mp.FrameRenderer(use, cam, st)
+        split = bool(rng.random() < 0.4 and spp > 1)
+        if split:   # progressive split
+            cut = int(rng.integers(1, spp)); nxt = fr.render_pass(0, cut); gseg = int(fr.segments.item()); fr.render_pass(nxt); gseg += int(fr.segments.item())
+        else:
+            fr.render(); gseg = int(fr.segments.item())
         img, u8 = fr.untile()
         torch.cuda.synchronize()
         if depth:
             of, ou8, _, seg = ob.render_image_paths_mt(smp, w, h, spp, seed, depth, ts, 8)
         else:
             of, ou8, _, seg, _ = ob.render_image_mt(smp, w, h, spp, seed, ts, 8)
-        ok = np.array_equal(bits(img.cpu().numpy()), bits(of)) and np.array_equal(u8.cpu().numpy(), ou8)
+        po.lib().mpo_set_chunked_sum(0)
+        ob.set_instances(np.zeros((0, 3), np.float32))
+        ok = np.array_equal(bits(img.cpu().numpy()), bits(of)) and np.array_equal(u8.cpu().numpy(), ou8) and gseg == seg
         if not ok:
             bad += 1
-            print(f"MISMATCH case {case}: {name} {w}x{h} ts{ts} spp{spp} seed{seed} mode {mode} depth {depth} S{s_opt} eye{eye} at{at} f{fnum}: "
+            print(f"MISMATCH case {case}: {name} {w}x{h} ts{ts} spp{spp} seed{seed} mode {mode} depth {depth} S{s_opt} chunked {chunked} inst {use is not scene} sky {sky} eye{eye} at{at} f{fnum}: "
                   f"{int(np.sum(bits(img.cpu().numpy()) != bits(of)))} f32 values differ")
     ctx.set_option("packet_samples_in_flight", 0)
     ctx.set_option("packet_stack_registers", 64)
