@@ -183,8 +183,10 @@ void mp_ctx_destroy(mp_ctx *ctx);
 int mp_ctx_device(const mp_ctx *ctx, int *device_id, int *cu_count);
 /* Tuning knobs.  "packet_stack_registers" (1..64, default 64): entries of the ray-packet walk's shared stack kept in registers; the
  * rest of the scene's stack bound lives in LDS.  "packet_samples_in_flight" (0 = automatic, or 1, 2, 4, ... 64): samples of one pixel
- * a wavefront traces per pass (64 / value pixels side by side); sets the size of a work unit.  Results never depend on either
- * (tests sweep them). */
+ * a wavefront traces per pass (64 / value pixels side by side); sets the size of a work unit.  "packet_rays_per_lane" (1 default,
+ * or 2): 2 = 128-ray walks, two rays per lane (measured slower on MI355X; kept as the measured alternative).  "blocks_per_cu"
+ * (0 = as many as fit, or 1..8): resident workgroups per CU, a diagnostic knob for occupancy studies.  Results never depend on
+ * any of them (tests sweep them). */
 int mp_ctx_set_option(mp_ctx *ctx, const char *key, int value);
 
 /* ---- camera.rs ------------------------------------------------------------------------------------------ */

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -76,6 +77,7 @@ struct mp_ctx {
     std::atomic<uint32_t> next_counter{0};
     std::atomic<uint32_t> packet_stack_regs{64};
     std::atomic<uint32_t> packet_samples{0};  // 0 = chosen by the launcher
+    std::atomic<uint32_t> rays_per_lane{1};   // packet kernel: 1 = 64-ray walks, 2 = 128-ray walks (two rays per lane)
     std::atomic<uint32_t> blocks_per_cu{0};   // 0 = as many as fit (diagnostic knob: resident workgroups per CU)
     uint32_t* take_counter() {  // one set of work-queue heads per launch in flight
         return d_counters + static_cast<size_t>(next_counter.fetch_add(1, std::memory_order_relaxed) % kCounters) * kWorkQueues * kWorkQueueStride;
@@ -503,6 +505,7 @@ int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_samp
     L.scene = scene->dev;
     L.scene.packet_stack_regs = ctx->packet_stack_regs.load();
     L.packet_samples = ctx->packet_samples.load();
+    L.rays_per_lane = ctx->rays_per_lane.load();
     L.sampler = sampler;
     L.width = st.width;
     L.height = st.height;
@@ -513,7 +516,10 @@ int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_samp
     L.n_tiles = static_cast<uint32_t>(n);
     L.d_out = d_out;
     L.d_counter = ctx->take_counter();
-    L.cu_count = ctx->cu_count;
+    {   // diagnostic knob: fewer resident workgroups per CU (the launchers size their grids as cu_count x blocks that fit)
+        const uint32_t bpc = ctx->blocks_per_cu.load();
+        L.cu_count = bpc ? std::max(1, ctx->cu_count * static_cast<int>(bpc) / 8) : ctx->cu_count;
+    }
     L.traversal = (st.flags & MP_FLAG_TRAVERSAL_GROUPS) ? 1 : 0;
     L.max_depth = (st.flags & MP_FLAG_PATHS) ? st.max_depth : 0u;
     L.d_segments = reinterpret_cast<unsigned long long*>(d_segments);
@@ -583,6 +589,11 @@ int mp_ctx_set_option(mp_ctx* ctx, const char* key, int value) {
     if (std::strcmp(key, "packet_stack_registers") == 0) {
         if (value < 1 || value > 64) return fail(MP_ERR_INVALID, "packet_stack_registers must be in 1..64");
         ctx->packet_stack_regs.store(static_cast<uint32_t>(value));
+        return MP_OK;
+    }
+    if (std::strcmp(key, "packet_rays_per_lane") == 0) {
+        if (value != 1 && value != 2) return fail(MP_ERR_INVALID, "packet_rays_per_lane must be 1 or 2");
+        ctx->rays_per_lane.store(static_cast<uint32_t>(value));
         return MP_OK;
     }
     if (std::strcmp(key, "blocks_per_cu") == 0) {

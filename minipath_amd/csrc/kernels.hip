@@ -813,6 +813,178 @@ __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, b
     trace_packet_impl<1, -1>(sc, r, active, st, hit);
 }
 
+// ---- two rays per lane: 128 rays share one walk (opt-in: mp_ctx_set_option "packet_rays_per_lane" = 2) --------------------
+// The walk's scalar work (record fetches, loop control, pops and pushes) does not depend on how many rays ride on it, and the
+// scalar ALU is the unit the 64-ray walk saturates first (profiles/r02_notes.md).  Here every lane carries TWO rays (A and B: the
+// same sample index in two pixels two columns apart), so the scalar work per ray halves and each fetched record feeds two
+// independent vector dependency chains.  Per-ray decisions are exactly those of trace_packet_impl (same operations on the same
+// operands: the frame is bit-identical, tested); an entry is visited while any ray of either set needs it.
+// MEASURED SLOWER than the 64-ray walk on MI355X (metric's frame: 52.9 ms at 6 waves / 80 VGPRs, 54.2 at 5, 56.5 at 4, against
+// 48.6 ms; teapot 13.5 against 12.4): the union of two 2x2-pixel packets is visited by twice the vector work, the wave-level
+// early-outs fire less often, and the 80-VGPR budget spills in the pop loop.  Kept as the measured alternative, not the default.
+struct RegStack2 {
+    int link, src, alo, ahi, blo, bhi;
+    __device__ __forceinline__ RegStack2() : link(0), src(0), alo(0), ahi(0), blo(0), bhi(0) {}
+    __device__ __forceinline__ void push(int sp, uint32_t l, uint32_t s, uint64_t ma, uint64_t mb) {
+        asm volatile(
+            "s_mov_b32 m0, %6\n\ts_nop 0\n\t"
+            "v_writelane_b32 %0, %7, m0\n\tv_writelane_b32 %1, %8, m0\n\tv_writelane_b32 %2, %9, m0\n\tv_writelane_b32 %3, %10, m0\n\t"
+            "v_writelane_b32 %4, %11, m0\n\tv_writelane_b32 %5, %12, m0"
+            : "+v"(link), "+v"(src), "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi)
+            : "s"(sp), "s"(l), "s"(s), "s"(static_cast<uint32_t>(ma)), "s"(static_cast<uint32_t>(ma >> 32)),
+              "s"(static_cast<uint32_t>(mb)), "s"(static_cast<uint32_t>(mb >> 32))
+            : "m0");
+    }
+    __device__ __forceinline__ void pop(int sp, uint32_t& l, uint32_t& s, uint64_t& ma, uint64_t& mb) const {
+        l = static_cast<uint32_t>(__builtin_amdgcn_readlane(link, sp));
+        s = static_cast<uint32_t>(__builtin_amdgcn_readlane(src, sp));
+        ma = static_cast<uint32_t>(__builtin_amdgcn_readlane(alo, sp)) |
+             (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(ahi, sp))) << 32);
+        mb = static_cast<uint32_t>(__builtin_amdgcn_readlane(blo, sp)) |
+             (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(bhi, sp))) << 32);
+    }
+};
+
+template <int MODE, int OCT>
+__device__ __forceinline__ void trace_packet2_impl(const DevScene& sc, const Ray& ra, const Ray& rb, bool active_a, bool active_b,
+                                                   PacketHit& hit_a, PacketHit& hit_b) {
+    constexpr bool PATCH_NAN = MODE == 2;
+    kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
+    kfp tris = (kfp)(uintptr_t)sc.tris_aos;
+    RegStack2 st;
+    float best_a = FLT_MAX, ua = 0.0f, va = 0.0f, best_b = FLT_MAX, ub = 0.0f, vb = 0.0f;  // best (:34-37), per ray
+    uint32_t prim_a = kNoPrim, prim_b = kNoPrim;
+    st.push(0, sc.root, kSrcRoot, __ballot(active_a), __ballot(active_b));  // entry 0 = root (:28-32), never culled
+    int sp = 1;
+    int stale_top = 0;  // entries [0, stale_top) were pushed before some ray's best.t last changed
+    while (sp > 0) {
+        sp--;
+        uint32_t link, src;
+        uint64_t onm_a, onm_b;  // rays of each set this entry is still live for
+        st.pop(sp, link, src, onm_a, onm_b);
+        if (sp < stale_top) {  // :40-44, per ray
+            stale_top = sp;
+            kfp bx = nodes + static_cast<size_t>(src) * 8;
+            const float b0 = bx[0], b1 = bx[1], b2 = bx[2], b3 = bx[3], b4 = bx[4], b5 = bx[5];
+            onm_a &= ~mask_gt(slab_entry<PATCH_NAN, OCT>(b0, b1, b2, b3, b4, b5, ra), best_a);
+            onm_b &= ~mask_gt(slab_entry<PATCH_NAN, OCT>(b0, b1, b2, b3, b4, b5, rb), best_b);
+        }
+        if ((onm_a | onm_b) == 0) continue;
+        const bool on_a = __builtin_amdgcn_inverse_ballot_w64(onm_a), on_b = __builtin_amdgcn_inverse_ballot_w64(onm_b);
+        float lim_a = on_a ? best_a : -1.0f, lim_b = on_b ? best_b : -1.0f;  // nothing passes for a disabled ray
+        if ((link & 63u) == 0u) {
+            // InnerNode::intersect :149-162, children ascending; record = {min.xyz, max.xyz, dlink, n}
+            const uint32_t node = link >> 6;
+            kfp nd = nodes + static_cast<size_t>(node) * 64;
+            float a0 = nd[0], a1 = nd[1], a2 = nd[2], a3 = nd[3], a4 = nd[4], a5 = nd[5], a6 = nd[6];
+            const uint32_t nchild = uniform_u(nd[7]);
+            uint32_t slot = node * 8u;
+            auto child = [&](const float b0, const float b1, const float b2, const float b3, const float b4, const float b5,
+                             const float blink, const uint32_t cslot) {
+                const uint32_t cl = uniform_u(blink);
+                if (cl == MP_LINK_NULL) return;  // Null links are skipped at pop in the reference (:49)
+                float t1a, t2a, t1b, t2b;
+                slab<PATCH_NAN, OCT>(b0, b1, b2, b3, b4, b5, ra, lim_a, t1a, t2a);
+                slab<PATCH_NAN, OCT>(b0, b1, b2, b3, b4, b5, rb, lim_b, t1b, t2b);
+                const uint64_t ok_a = __ballot(t1a <= t2a), ok_b = __ballot(t1b <= t2b);
+                if ((ok_a | ok_b) != 0) {
+                    st.push(sp, cl, cslot, ok_a, ok_b);
+                    sp++;
+                }
+            };
+            for (uint32_t p = nchild >> 1; p > 0; p--) {
+                const float b0 = nd[8], b1 = nd[9], b2 = nd[10], b3 = nd[11], b4 = nd[12], b5 = nd[13], b6 = nd[14];
+                child(a0, a1, a2, a3, a4, a5, a6, slot);
+                a0 = nd[16]; a1 = nd[17]; a2 = nd[18]; a3 = nd[19]; a4 = nd[20]; a5 = nd[21]; a6 = nd[22];
+                child(b0, b1, b2, b3, b4, b5, b6, slot + 1u);
+                slot += 2u;
+                nd += 16;
+            }
+            if (nchild & 1u) child(a0, a1, a2, a3, a4, a5, a6, slot);
+        } else {
+            // intersect_triangles :104-140 for both rays of every lane
+            const uint32_t first = link >> 6, n_real = link & 63u;
+            kfp tp = tris + static_cast<size_t>(first) * (8 * kTriDwords);
+            const float thr_a = on_a ? -kTiny : INFINITY, thr_b = on_b ? -kTiny : INFINITY;
+            uint64_t changed = 0;
+            auto test = [&](const float v0x, const float v0y, const float v0z, const float e1x, const float e1y, const float e1z,
+                            const float e2x, const float e2y, const float e2z, const uint32_t tri) {
+                // triangle.rs:183-217, ray A and ray B side by side (see trace_packet_impl for the early-out argument)
+                const float hxa = fms(ra.dy, e2z, ra.dz * e2y), hya = fms(ra.dz, e2x, ra.dx * e2z), hza = fms(ra.dx, e2y, ra.dy * e2x);
+                const float hxb = fms(rb.dy, e2z, rb.dz * e2y), hyb = fms(rb.dz, e2x, rb.dx * e2z), hzb = fms(rb.dx, e2y, rb.dy * e2x);
+                const float det_a = fma_dot(e1x, e1y, e1z, hxa, hya, hza), det_b = fma_dot(e1x, e1y, e1z, hxb, hyb, hzb);
+                const float sxa = ra.ox - v0x, sya = ra.oy - v0y, sza = ra.oz - v0z;
+                const float sxb = rb.ox - v0x, syb = rb.oy - v0y, szb = rb.oz - v0z;
+                const float un_a = fma_dot(sxa, sya, sza, hxa, hya, hza), un_b = fma_dot(sxb, syb, szb, hxb, hyb, hzb);
+                const uint32_t sg_a = as_u(det_a) & 0x80000000u, sg_b = as_u(det_b) & 0x80000000u;
+                const bool ok_a = fabsf(det_a) <= kHuge, ok_b = fabsf(det_b) <= kHuge;
+                const float xua = ok_a ? as_f(as_u(un_a) ^ sg_a) : 1.0f, xub = ok_b ? as_f(as_u(un_b) ^ sg_b) : 1.0f;
+                if ((__ballot(!(xua <= thr_a)) | __ballot(!(xub <= thr_b))) == 0) return;  // no live ray of either set can have u >= 0
+                const float qxa = fms(sya, e1z, sza * e1y), qya = fms(sza, e1x, sxa * e1z), qza = fms(sxa, e1y, sya * e1x);
+                const float qxb = fms(syb, e1z, szb * e1y), qyb = fms(szb, e1x, sxb * e1z), qzb = fms(sxb, e1y, syb * e1x);
+                const float vn_a = fma_dot(ra.dx, ra.dy, ra.dz, qxa, qya, qza), vn_b = fma_dot(rb.dx, rb.dy, rb.dz, qxb, qyb, qzb);
+                const float tn_a = fma_dot(e2x, e2y, e2z, qxa, qya, qza), tn_b = fma_dot(e2x, e2y, e2z, qxb, qyb, qzb);
+                const float xva = ok_a ? as_f(as_u(vn_a) ^ sg_a) : 1.0f, xta = ok_a ? as_f(as_u(tn_a) ^ sg_a) : 1.0f;
+                const float xvb = ok_b ? as_f(as_u(vn_b) ^ sg_b) : 1.0f, xtb = ok_b ? as_f(as_u(tn_b) ^ sg_b) : 1.0f;
+                if ((__ballot(!(fminf(fminf(xua, xva), xta) <= thr_a)) | __ballot(!(fminf(fminf(xub, xvb), xtb) <= thr_b))) == 0) return;
+                const float inv_a = 1.0f / det_a, inv_b = 1.0f / det_b;
+                const float u_a = inv_a * un_a, v_a = inv_a * vn_a, t_a = inv_a * tn_a;
+                const float u_b = inv_b * un_b, v_b = inv_b * vn_b, t_b = inv_b * tn_b;
+                const bool acc_a = (u_a >= 0.0f) & (v_a >= 0.0f) & ((u_a + v_a) <= 1.0f) & (t_a >= 0.0f) & (t_a < lim_a);
+                const bool acc_b = (u_b >= 0.0f) & (v_b >= 0.0f) & ((u_b + v_b) <= 1.0f) & (t_b >= 0.0f) & (t_b < lim_b);
+                best_a = acc_a ? t_a : best_a; lim_a = acc_a ? t_a : lim_a; ua = acc_a ? u_a : ua; va = acc_a ? v_a : va; prim_a = acc_a ? tri : prim_a;
+                best_b = acc_b ? t_b : best_b; lim_b = acc_b ? t_b : lim_b; ub = acc_b ? u_b : ub; vb = acc_b ? v_b : vb; prim_b = acc_b ? tri : prim_b;
+                changed |= __ballot(acc_a) | __ballot(acc_b);
+            };
+            float a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3], a4 = tp[4], a5 = tp[5], a6 = tp[6], a7 = tp[7], a8 = tp[8];
+            uint32_t tri = first * 8u;
+            for (uint32_t p = n_real >> 1; p > 0; p--) {
+                const float b0 = tp[9], b1 = tp[10], b2 = tp[11], b3 = tp[12], b4 = tp[13], b5 = tp[14], b6 = tp[15], b7 = tp[16], b8 = tp[17];
+                test(a0, a1, a2, a3, a4, a5, a6, a7, a8, tri);
+                a0 = tp[18]; a1 = tp[19]; a2 = tp[20]; a3 = tp[21]; a4 = tp[22]; a5 = tp[23]; a6 = tp[24]; a7 = tp[25]; a8 = tp[26];
+                test(b0, b1, b2, b3, b4, b5, b6, b7, b8, tri + 1u);
+                tri += 2u;
+                tp += 2 * kTriDwords;
+            }
+            if (n_real & 1u) test(a0, a1, a2, a3, a4, a5, a6, a7, a8, tri);
+            if (changed != 0) stale_top = sp;
+        }
+    }
+    hit_a.t = best_a; hit_a.u = ua; hit_a.v = va; hit_a.prim = prim_a;
+    hit_b.t = best_b; hit_b.u = ub; hit_b.v = vb; hit_b.prim = prim_b;
+}
+
+__device__ __forceinline__ void trace_packet2(const DevScene& sc, const Ray& ra, const Ray& rb, bool act_a, bool act_b, PacketHit& ha,
+                                              PacketHit& hb) {
+    const bool slow = (act_a && (fabsf(ra.ix) == INFINITY || fabsf(ra.iy) == INFINITY || fabsf(ra.iz) == INFINITY)) ||
+                      (act_b && (fabsf(rb.ix) == INFINITY || fabsf(rb.iy) == INFINITY || fabsf(rb.iz) == INFINITY));
+    if (__ballot(slow) != 0) {
+        trace_packet2_impl<2, -1>(sc, ra, rb, act_a, act_b, ha, hb);
+        return;
+    }
+    if (sc.boxes_ordered) {
+        // wave-uniform octant over BOTH ray sets
+        const uint64_t am = __ballot(act_a), bm = __ballot(act_b);
+        const uint64_t nxa = __ballot(act_a && ra.ix < 0.0f), nya = __ballot(act_a && ra.iy < 0.0f), nza = __ballot(act_a && ra.iz < 0.0f);
+        const uint64_t nxb = __ballot(act_b && rb.ix < 0.0f), nyb = __ballot(act_b && rb.iy < 0.0f), nzb = __ballot(act_b && rb.iz < 0.0f);
+        const bool xn = (nxa | nxb) != 0, yn = (nya | nyb) != 0, zn = (nza | nzb) != 0;
+        const bool xu = !xn || (nxa == am && nxb == bm), yu = !yn || (nya == am && nyb == bm), zu = !zn || (nza == am && nzb == bm);
+        if (xu && yu && zu) {
+            switch ((xn ? 1 : 0) | (yn ? 2 : 0) | (zn ? 4 : 0)) {
+                case 0: trace_packet2_impl<1, 0>(sc, ra, rb, act_a, act_b, ha, hb); return;
+                case 1: trace_packet2_impl<1, 1>(sc, ra, rb, act_a, act_b, ha, hb); return;
+                case 2: trace_packet2_impl<1, 2>(sc, ra, rb, act_a, act_b, ha, hb); return;
+                case 3: trace_packet2_impl<1, 3>(sc, ra, rb, act_a, act_b, ha, hb); return;
+                case 4: trace_packet2_impl<1, 4>(sc, ra, rb, act_a, act_b, ha, hb); return;
+                case 5: trace_packet2_impl<1, 5>(sc, ra, rb, act_a, act_b, ha, hb); return;
+                case 6: trace_packet2_impl<1, 6>(sc, ra, rb, act_a, act_b, ha, hb); return;
+                default: trace_packet2_impl<1, 7>(sc, ra, rb, act_a, act_b, ha, hb); return;
+            }
+        }
+    }
+    trace_packet2_impl<1, -1>(sc, ra, rb, act_a, act_b, ha, hb);
+}
+
 // pixel_sum += sample, strictly in sample order (worker.rs:41-43), for the S samples of a pixel held by S consecutive lanes.
 // S = 16 is one DPP row: v_add_f32_dpp with row_newbcast:j adds lane j of the row in ONE instruction (no LDS permute); every
 // lane of the row ends with the same sum.  Inactive samples contribute +0.0 (exact).
@@ -917,6 +1089,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
             if (P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) chunk_flush(P, off, inpix && sub == 0, acc);
         }
         if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
+        if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
+    }
+}
+
+// Fused tile render on 128-ray packets (two rays per lane, trace_packet2).  A wave owns a 4x2 block of pixels and shoots 16
+// consecutive samples of each pixel per pass: lane = (pixel of the left 2x2 half) * 16 + sub-sample carries that sample of its
+// pixel (ray A) and of the pixel two columns to the right (ray B).  Reference semantics only (the path kernel has its own loop);
+// TriangleBvh scenes whose stack bound fits the register stack.
+template <int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void render_tiles_packet2_kernel(RenderParams P) {
+    constexpr int S = 16;
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const int pix = lane / S, sub = lane % S;
+    const uint64_t pixel_lanes = ((1ull << S) - 1ull) << (lane & ~(S - 1));
+    const uint32_t ts = P.tile_size;
+    const uint32_t bx = (ts + 3) / 4, by = (ts + 1) / 2, upt = bx * by, total = P.n_tiles * upt;
+    uint32_t qstate = blockIdx.x % kWorkQueues;
+    for (;;) {
+        MP_NEXT_UNIT(unit)
+        const uint32_t b = unit % upt;
+        const uint32_t tile_i = P.tile_order ? P.tile_order[unit / upt] : unit / upt;
+        const uint64_t t_unit = P.tile_cost ? __builtin_readcyclecounter() : 0;
+        const mp_block T = P.tiles[tile_i];
+        const uint32_t px_a = T.min_x + (b % bx) * 4 + static_cast<uint32_t>(pix % 2), px_b = px_a + 2u;
+        const uint32_t py = T.min_y + (b / bx) * 2 + static_cast<uint32_t>(pix / 2);
+        const bool in_a = px_a < T.max_x && py < T.max_y, in_b = px_b < T.max_x && py < T.max_y;
+        if (__ballot(in_a) == 0) continue;  // B lies to the right of A: no A pixel, no B pixel
+        const size_t off_a = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px_a - T.min_x)) * 4;
+        const size_t off_b = off_a + 8;
+        float acc_a, cnt_a, acc_b, cnt_b;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
+        pixel_state_load(P, off_a, in_a, sub == 0, acc_a, cnt_a);
+        pixel_state_load(P, off_b, in_b, sub == 0, acc_b, cnt_b);
+        for (uint32_t s0 = P.s_begin & ~static_cast<uint32_t>(S - 1); s0 < P.s_end; s0 += S) {
+            const uint32_t s = s0 + static_cast<uint32_t>(sub);
+            const bool in_pass = s >= P.s_begin && s < P.s_end;
+            const bool act_a = in_a && in_pass, act_b = in_b && in_pass;
+            Ray ra, rb;
+            ra.ox = ra.oy = ra.oz = ra.dx = ra.dy = ra.dz = ra.ix = ra.iy = ra.iz = 0.0f;
+            rb = ra;
+            if (act_a) sample_ray(P.gen, px_a, py, s, ra);
+            if (act_b) sample_ray(P.gen, px_b, py, s, rb);
+            const bool go_a = act_a && may_hit_scene(P.scene, ra), go_b = act_b && may_hit_scene(P.scene, rb);
+            PacketHit ha, hb;
+            ha.t = FLT_MAX; ha.u = ha.v = 0.0f; ha.prim = kNoPrim;
+            hb = ha;
+            if ((__ballot(go_a) | __ballot(go_b)) != 0) trace_packet2(P.scene, ra, rb, go_a, go_b, ha, hb);
+            float c_a = 0.0f, c_b = 0.0f;
+            const bool hit_a = ha.prim != kNoPrim, hit_b = hb.prim != kNoPrim;
+            if (hit_a) {
+                float nn[3];
+                resolve_normal(P.scene, ha.prim, ha.u, ha.v, nn);
+                c_a = fabsf(ra.dx * nn[0] + ra.dy * nn[1] + ra.dz * nn[2]);  // worker.rs:60
+            }
+            if (hit_b) {
+                float nn[3];
+                resolve_normal(P.scene, hb.prim, hb.u, hb.v, nn);
+                c_b = fabsf(rb.dx * nn[0] + rb.dy * nn[1] + rb.dz * nn[2]);
+            }
+            cnt_a += static_cast<float>(__popcll(__ballot(hit_a) & pixel_lanes));
+            cnt_b += static_cast<float>(__popcll(__ballot(hit_b) & pixel_lanes));
+            add_samples_in_order<S>(acc_a, c_a, lane);  // misses add +0.0 (exact)
+            add_samples_in_order<S>(acc_b, c_b, lane);
+            if (P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) {
+                chunk_flush(P, off_a, in_a && sub == 0, acc_a);
+                chunk_flush(P, off_b, in_b && sub == 0, acc_b);
+            }
+        }
+        if (sub == 0) {
+            if (in_a) pixel_state_store(P, off_a, acc_a, cnt_a);
+            if (in_b) pixel_state_store(P, off_b, acc_b, cnt_b);
+        }
         if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
     }
 }
@@ -1576,6 +1819,13 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     const uint32_t plds = P.lds_per_wave * 4;
     if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
     const uint32_t per_cu = plds ? std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds)) : 8u;
+    if (S == 16 && L.rays_per_lane == 2 && !lds_stack && L.scene.kind == 0u && L.scene.stack_cap <= 64u) {
+        // 128-ray walks: two rays per lane (8-pixel units)
+        const uint64_t units2 = static_cast<uint64_t>(L.n_tiles) * ((L.tile_size + 3) / 4) * ((L.tile_size + 1) / 2);
+        const uint32_t grid2 = static_cast<uint32_t>(std::min<uint64_t>((units2 + 3) / 4, static_cast<uint64_t>(L.cu_count) * 8));
+        hipLaunchKernelGGL((render_tiles_packet2_kernel<6>), dim3(grid2), dim3(256), 0, st, P);
+        return check(hipGetLastError(), "render_tiles_packet2_kernel launch", err);
+    }
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want * S, static_cast<uint64_t>(L.cu_count) * per_cu));
     // scenes whose traversal arrays exceed the 16 KB scalar data cache by far run 8 waves per SIMD
     const bool big = (static_cast<uint64_t>(L.scene.inner_count) * 256u + static_cast<uint64_t>(L.scene.packet_count) * 384u) > (1u << 20);

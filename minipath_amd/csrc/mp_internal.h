@@ -128,6 +128,7 @@ struct RenderLaunch {
     bool carry_in = false, finalize = true;
     bool chunked = false;         // MP_FLAG_CHUNKED_SUM
     uint32_t packet_samples = 0;  // samples of a pixel in flight per pass of the packet kernel (0 = automatic)
+    uint32_t rays_per_lane = 1;   // 2: 128-ray walks (render_tiles_packet2_kernel) where applicable
     const uint32_t* d_tile_order = nullptr;      // optional: hand-out order of the tiles (device, n_tiles)
     unsigned long long* d_tile_cost = nullptr;   // optional: += shader-clock cycles spent per tile (device, n_tiles)
 };

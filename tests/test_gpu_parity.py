@@ -640,6 +640,40 @@ def test_progressive_passes_equal_single_launch(teapot, tmp_path, max_depth, tra
     assert rc != 0
 
 
+def test_two_rays_per_lane_walk_is_bit_identical(teapot, oracle, teapot_oracle_bvh):
+    """mp_ctx_set_option("packet_rays_per_lane", 2): 128-ray walks (two rays per lane, 4x2-pixel units) must give the frame of the
+    64-ray walk and of the oracle bit for bit, incl. clipped tiles, ragged progressive passes and the chunked accumulation rule."""
+    import torch
+
+    ctx = teapot.object.ctx
+    cam = mp.Camera.teapot_view()
+    res, spp = (250, 131), 37
+    of, ou8, *_ = teapot_oracle_bvh.render_image_mt(oracle.build_sampler(oracle.teapot_camera(), *res), res[0], res[1], spp, SEED, 32, 8)
+    try:
+        ctx.set_option("packet_rays_per_lane", 2)
+        st = mp.RenderSettings(32, spp, res, seed=SEED)
+        fr = mp.FrameRenderer(teapot, cam, st)
+        fr.render()
+        img, img8 = fr.untile()
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(img.cpu().numpy()), bits(of)) and np.array_equal(img8.cpu().numpy(), ou8)
+        pr = mp.FrameRenderer(teapot, cam, st)
+        nxt = 0
+        for count in (16, 5, 0):
+            nxt = pr.render_pass(nxt, count)
+        img2, _ = pr.untile()
+        torch.cuda.synchronize()
+        assert torch.equal(img2.view(torch.int32), img.view(torch.int32))
+        stc = mp.RenderSettings(32, 300, (64, 40), seed=SEED, chunked_sum=True)
+        two = mp.FrameRenderer(teapot, cam, stc); two.render(); a, _ = two.untile()
+        ctx.set_option("packet_rays_per_lane", 1)
+        one = mp.FrameRenderer(teapot, cam, stc); one.render(); b, _ = one.untile()
+        torch.cuda.synchronize()
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    finally:
+        ctx.set_option("packet_rays_per_lane", 1)
+
+
 def test_samples_in_flight_do_not_change_the_frame(teapot, oracle, teapot_oracle_bvh):
     """The number of samples of a pixel a wavefront holds per pass (work-unit size; 16 = one DPP row with row_newbcast sums,
     others through lane shuffles) must not change a single bit: the per-pixel sum stays sequential in sample order."""
