@@ -161,11 +161,20 @@ __device__ __forceinline__ float fma_dot(float ax, float ay, float az, float bx,
 // util/simba.rs:61-67 : mul_sub(a, b, c) = a*b - c, c rounded first
 __device__ __forceinline__ float fms(float a, float b, float c) { return __builtin_fmaf(a, b, -c); }
 
+// Lane masks straight from the compare unit (v_cmp writes the 64-bit mask; no bool -> int -> ballot round trip, which costs two
+// VALU per use): LLVM CmpInst predicate numbers.
+constexpr int kFcmpOGT = 2, kFcmpOGE = 3, kFcmpOLT = 4, kFcmpOLE = 5;
+__device__ __forceinline__ uint64_t mask_gt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOGT); }
+__device__ __forceinline__ uint64_t mask_lt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOLT); }
+__device__ __forceinline__ uint64_t mask_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOLE); }
+__device__ __forceinline__ uint64_t mask_ge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOGE); }
+
 // Traces `nrays` rays held in the wave's LDS queue `q` (rows ox,oy,oz,dx,dy,dz; slot = column).
 // On return rows 0..3 of each slot hold the closest hit: t (f32::MAX on miss), prim (bits), u, v.
 // impl Object for TriangleBvh::intersect, ray_bvh_intersection.rs:26-96, for 8 rays at a time.
-__device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict__ q, uint2* __restrict__ stack_base,
-                                           int nrays) {
+template <bool PATCH_NAN>
+__device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __restrict__ q, uint2* __restrict__ stack_base,
+                                                int nrays) {
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const int g = lane >> 3, li = lane & 7;
     uint2* stack = stack_base + g * sc.stack_cap;
@@ -241,13 +250,20 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
                     float ax = (c0.x - ox) * ix, ay = (c0.y - oy) * iy, az = (c0.z - oz) * iz;
                     float cx = (c0.w - ox) * ix, cy = (c1.x - oy) * iy, cz = (c1.y - oz) * iz;
                     // NaN (0 * inf) -> -inf on the min side, +inf on the max side (aabb.rs:262-267): maxNum / minNum return the
-                    // other operand for a NaN and the value itself otherwise, one instruction each and no branch
-                    ax = fmaxf(ax, -INFINITY); ay = fmaxf(ay, -INFINITY); az = fmaxf(az, -INFINITY);
-                    cx = fminf(cx, INFINITY); cy = fminf(cy, INFINITY); cz = fminf(cz, INFINITY);
+                    // other operand for a NaN and the value itself otherwise, one instruction each and no branch.  Only a ray with
+                    // a zero direction component (infinite inverse) can produce one: queues without such a ray run the variant
+                    // without the six patches (trace_wave)
+                    if (PATCH_NAN) {
+                        ax = fmaxf(ax, -INFINITY); ay = fmaxf(ay, -INFINITY); az = fmaxf(az, -INFINITY);
+                        cx = fminf(cx, INFINITY); cy = fminf(cy, INFINITY); cz = fminf(cz, INFINITY);
+                    }
                     const float t1 = fmaxf(fmaxf(fminf(ax, cx), 0.0f), fmaxf(fminf(ay, cy), fminf(az, cz)));
                     const float t2 = fminf(fminf(fmaxf(ax, cx), best_t), fminf(fmaxf(ay, cy), fmaxf(az, cz)));
-                    bool ok = (t1 <= t2) && (child != MP_LINK_NULL);  // Null links are skipped at pop in the reference (:49)
-                    uint32_t m = static_cast<uint32_t>(__ballot(ok) >> (g * 8)) & 0xFFu;
+                    // Null links are skipped at pop in the reference (:49).  The lane mask comes straight from the compare unit;
+                    // lanes outside this branch contribute garbage bits to other groups' bytes, which are never looked at
+                    const uint64_t okm = mask_le(t1, t2) & __builtin_amdgcn_uicmp(child, MP_LINK_NULL, 33);  // 33 = ICMP_NE
+                    const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
+                    uint32_t m = static_cast<uint32_t>(okm >> (g * 8)) & 0xFFu;
                     if (ok) stack[sp + __popc(m & lanes_below)] = make_uint2(child, as_u(t1));  // ascending lane :161
                     sp += __popc(m);
                 } else {
@@ -277,6 +293,15 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
         }
     }
     wave_lds_sync();
+}
+
+// A queue without a ray that has a zero direction component cannot produce 0 * inf in the slab test: it runs the variant
+// without the NaN patches (six VALU per node step less).  Wave-uniform choice per call.
+__device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict__ q, uint2* __restrict__ stack_base, int nrays) {
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const bool zero = lane < nrays && (q[3 * 64 + lane] == 0.0f || q[4 * 64 + lane] == 0.0f || q[5 * 64 + lane] == 0.0f);
+    if (__ballot(zero) != 0) trace_wave_impl<true>(sc, q, stack_base, nrays);
+    else trace_wave_impl<false>(sc, q, stack_base, nrays);
 }
 
 // Exact conservative pre-test against the union of the root node's child boxes (DevScene::pre_min/pre_max): every
@@ -539,14 +564,6 @@ typedef const __attribute__((address_space(4))) uint32_t* kup;
 
 constexpr float kTiny = 9.094947017729282e-13f;  // 2^-40
 constexpr float kHuge = 1099511627776.0f;        // 2^40
-
-// Lane masks straight from the compare unit (v_cmp writes the 64-bit mask; no bool -> int -> ballot round trip, which costs two
-// VALU per use): LLVM CmpInst predicate numbers.
-constexpr int kFcmpOGT = 2, kFcmpOGE = 3, kFcmpOLT = 4, kFcmpOLE = 5;
-__device__ __forceinline__ uint64_t mask_gt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOGT); }
-__device__ __forceinline__ uint64_t mask_lt(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOLT); }
-__device__ __forceinline__ uint64_t mask_le(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOLE); }
-__device__ __forceinline__ uint64_t mask_ge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, kFcmpOGE); }
 
 // Lane mask of the rays for which sign(num) != sign(det) and the quotient fl(fl(1/det) * num) is certainly a non-zero negative
 // number (|num| >= 2^-40 and |det| <= 2^40 keep |quotient| >= 2^-80(1-eps): no underflow to -0, which would pass `>= 0`).
