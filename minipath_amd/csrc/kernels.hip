@@ -191,6 +191,14 @@ __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __res
     float best_t = FLT_MAX;                 // best.t, group-uniform (ray_bvh_intersection.rs:34-37)
     float tl = FLT_MAX, ul = 0, vl = 0;     // this lane's earliest closest candidate
     uint32_t pkl = kNoPrim, seql = 0;
+    // inv_direction as Ray::new has it (geometry/mod.rs:49-53) for the ray in queue slot `lane`, computed ONCE here for all 64
+    // slots in parallel (three IEEE divisions per call instead of three per refill step); a group fetches its ray's inverse with
+    // ds_bpermute when it pulls the ray.  Not queued in LDS: three rows more per wave would cost a resident wave on deep trees.
+    float pix, piy, piz;
+    {
+        const float qx = q[3 * 64 + lane], qy = q[4 * 64 + lane], qz = q[5 * 64 + lane];
+        pix = (qx == 0.0f) ? INFINITY : 1.0f / qx; piy = (qy == 0.0f) ? INFINITY : 1.0f / qy; piz = (qz == 0.0f) ? INFINITY : 1.0f / qz;
+    }
 
     for (;;) {
         // -- ray finished: resolve the winner among the 8 lanes.  The reference takes candidates in (packet visit
@@ -219,12 +227,13 @@ __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __res
             uint64_t gm = idle & 0x0101010101010101ull;
             int mine = head + __popcll(gm & groups_below);
             head += __popcll(gm);
+            // (ds_bpermute reads the source lane's register whether or not that lane is enabled; an out-of-range `mine` wraps)
+            const float fix = __shfl(pix, mine & 63), fiy = __shfl(piy, mine & 63), fiz = __shfl(piz, mine & 63);
             if (slot < 0 && mine < nrays) {
                 slot = mine;
                 ox = q[0 * 64 + mine]; oy = q[1 * 64 + mine]; oz = q[2 * 64 + mine];
                 dx = q[3 * 64 + mine]; dy = q[4 * 64 + mine]; dz = q[5 * 64 + mine];
-                // inv_direction as Ray::new has it (geometry/mod.rs:49-53), recomputed rather than queued: 3 LDS rows less per wave
-                ix = (dx == 0.0f) ? INFINITY : 1.0f / dx; iy = (dy == 0.0f) ? INFINITY : 1.0f / dy; iz = (dz == 0.0f) ? INFINITY : 1.0f / dz;
+                ix = fix; iy = fiy; iz = fiz;
                 best_t = FLT_MAX; tl = FLT_MAX; ul = 0; vl = 0; pkl = kNoPrim; seql = 0; seq = 0;
                 pk = pk_end = 0;
                 sp = 1;
