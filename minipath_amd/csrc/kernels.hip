@@ -1231,7 +1231,7 @@ __device__ __forceinline__ bool path_vertex(const DevScene& sc, const PacketHit&
 }
 
 template <int S>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void render_paths_kernel(RenderParams P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void render_paths_kernel(RenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : 2;
     constexpr int BH = 64 / S / BW;
