@@ -671,7 +671,7 @@ int mp_tile_ordering(mp_block block, uint32_t tile_size, uint64_t shuffle_seed, 
     if (!n) return fail(MP_ERR_INVALID, "n is NULL");
     std::vector<mp_block> t = tile_ordering(block, tile_size, shuffle_seed);
     *n = t.size();
-    if (out) std::memcpy(out, t.data(), std::min(cap, t.size()) * sizeof(mp_block));
+    if (out && !t.empty() && cap) std::memcpy(out, t.data(), std::min(cap, t.size()) * sizeof(mp_block));
     return MP_OK;
     });
 }

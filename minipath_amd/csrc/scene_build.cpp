@@ -109,7 +109,8 @@ class Builder {
         // SplittingBin::sah cost factor per packet count (building.rs:358-383); read-only once built
         const size_t max_pc = (static_cast<size_t>(nt) + kPacket - 1) / kPacket;
         packet_cost_.resize(max_pc + 1);
-        for (size_t p = 0; p <= max_pc; p++) {
+        packet_cost_[0] = 0.0f;  // a group always holds at least one triangle: never read (ln(0) would make the depth below -inf)
+        for (size_t p = 1; p <= max_pc; p++) {
             const float B = 8.0f;
             float leaf_cost = (p <= 7) ? 0.75f * static_cast<float>(p) : std::numeric_limits<float>::infinity();
             float pf = static_cast<float>(p);

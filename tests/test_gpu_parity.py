@@ -759,6 +759,44 @@ def test_tile_list_cache_eviction(teapot, oracle, teapot_oracle_bvh):
             assert np.array_equal(bits(renderers[i].tile_buf[0].cpu().numpy()), bits(want)), (rounds, i)
 
 
+def test_tile_list_cache_eviction_under_two_threads(teapot, oracle, teapot_oracle_bvh):
+    """two host threads launching through one context with more distinct tile lists than the cache holds (each on
+    its own stream): a list evicted by one thread between the other thread's lookup and its launch must stay alive (the cache
+    hands out reference-counted entries).  Every tile must still be the oracle's."""
+    import threading
+
+    import torch
+
+    res, spp = (512, 512), 2
+    st = mp.RenderSettings(32, spp, res, seed=SEED)
+    cam = mp.Camera.teapot_view()
+    smp = oracle.build_sampler(oracle.teapot_camera(), *res)
+    lists = [[mp.ScreenBlock(32 * (i % 16), 32 * (i // 16) + 96, 32 * (i % 16) + 32, 32 * (i // 16) + 128)] for i in range(96)]
+    renderers = [mp.FrameRenderer(teapot, cam, st, tiles=tl) for tl in lists]
+    errors = []
+
+    def work(part):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    for fr in part:
+                        fr.render()
+            stream.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(renderers[k::2],)) for k in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for i in (0, 1, 33, 64, 95):
+        t = lists[i][0]
+        want, _ = teapot_oracle_bvh.render_tile(smp, res[0], res[1], spp, SEED, t.min_x, t.min_y, t.max_x, t.max_y)
+        assert np.array_equal(bits(renderers[i].tile_buf[0].cpu().numpy()), bits(want)), i
+
+
 def test_differential_fuzz(ctx):
     """tools/fuzz_gpu.py, bounded: random scenes / cameras (incl. axis-aligned views with zero direction components) / sizes /
     sample counts / kernels (packets, groups, fused paths, staged paths) / work-unit sizes / stack splits / progressive splits,
