@@ -574,14 +574,10 @@ typedef const __attribute__((address_space(4))) uint32_t* kup;
 constexpr float kTiny = 9.094947017729282e-13f;  // 2^-40
 constexpr float kHuge = 1099511627776.0f;        // 2^40
 
-// Lane mask of the rays for which sign(num) != sign(det) and the quotient fl(fl(1/det) * num) is certainly a non-zero negative
-// number (|num| >= 2^-40 and |det| <= 2^40 keep |quotient| >= 2^-80(1-eps): no underflow to -0, which would pass `>= 0`).
-// det = +-0 or subnormal gives an infinite reciprocal whose sign still follows det.  NaN never rejects.
-// `det_sign` = sign bit of det, `det_ok` = lanes with |det| <= 2^40: flipping num's sign by det's turns "signs differ and
-// |num| >= 2^-40" into one ordered compare.
-__device__ __forceinline__ uint64_t surely_negative_mask(float num, uint32_t det_sign, uint64_t det_ok) {
-    return det_ok & mask_le(as_f(as_u(num) ^ det_sign), -kTiny);
-}
+// Early-out argument of the triangle tests (trace_packet_impl): a numerator whose sign differs from det's, with |num| >= 2^-40 and
+// |det| <= 2^40, gives a quotient fl(fl(1/det) * num) that is certainly a non-zero negative number (|quotient| >= 2^-80(1-eps): no
+// underflow to -0, which would pass `>= 0`).  det = +-0 or subnormal gives an infinite reciprocal whose sign still follows det.
+// Flipping num's sign by det's turns "signs differ and |num| >= 2^-40" into one ordered compare against -2^-40; NaN never rejects.
 
 // OCT >= 0: every ray of the wave has a finite inverse direction with the sign pattern OCT (bit 0: x < 0, bit 1: y < 0,
 // bit 2: z < 0) and the box is ordered (min <= max, checked at upload).  IEEE subtraction and multiplication by a constant are
@@ -1841,7 +1837,7 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     if (nspp >= 32 && units * 16u < static_cast<uint64_t>(L.cu_count) * 32u * 24u) S = 32;
     if (L.packet_samples) S = static_cast<int>(std::min<uint32_t>(L.packet_samples, 64u));
     const bool lds_stack = L.scene.stack_cap > L.scene.packet_stack_regs;
-    P.lds_per_wave = lds_stack ? ((L.scene.stack_cap - L.scene.packet_stack_regs) * 20u + 15u) & ~15u : 0u;
+    P.lds_per_wave = lds_stack ? (L.scene.stack_cap - L.scene.packet_stack_regs) * 16u : 0u;  // one uint4 per entry beyond the register stack
     const uint32_t plds = P.lds_per_wave * 4;
     if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
     const uint32_t per_cu = plds ? std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds)) : 8u;
@@ -1891,7 +1887,7 @@ int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::stri
     P.segments = L.d_segments;
     P.chunked = L.chunked ? 1u : 0u;
     const bool lds_stack = L.scene.stack_cap > L.scene.packet_stack_regs;
-    P.lds_per_wave = lds_stack ? ((L.scene.stack_cap - L.scene.packet_stack_regs) * 20u + 15u) & ~15u : 0u;
+    P.lds_per_wave = lds_stack ? (L.scene.stack_cap - L.scene.packet_stack_regs) * 16u : 0u;  // one uint4 per entry beyond the register stack
     const uint32_t plds = P.lds_per_wave * 4;
     if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
     const uint32_t per_cu = plds ? std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds)) : 8u;
