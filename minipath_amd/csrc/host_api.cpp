@@ -1044,6 +1044,11 @@ int mp_render_frame_multi(mp_ctx* const* ctxs, const mp_scene* const* scenes, in
     if (ray_segments) *ray_segments = segs;  // reference semantics only (0 with MP_FLAG_PATHS: use mp_render_tiles_device_counted)
     // gather: every peer's shard travels over its own link to device 0, then one un-tile kernel there
     DeviceGuard g0(c0->device);
+    for (int r = 1; r < n; r++)  // direct xGMI copies instead of staging through the host; "already enabled" / unsupported are fine
+        if (ctxs[r]->device != c0->device) {
+            (void)hipDeviceEnablePeerAccess(ctxs[r]->device, 0);
+            (void)hipGetLastError();
+        }
     for (int r = 0; r < n; r++) {
         mp_ctx* c = ctxs[r];
         const size_t nt = shard[static_cast<size_t>(r)].size();
