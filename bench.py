@@ -168,7 +168,8 @@ def cpu_baseline(args, mp):
         "kind": "port",
         "sample": f"every {stride}th of the {ntiles} {args.tile}x{args.tile} tiles of the same frame at full {args.spp} spp "
                   f"({rays / 1e6:.1f} Mrays, {secs:.1f} s wall on {cores} threads); C restatement of the reference CPU path "
-                  "(8-lane loops that gcc -O3 -mavx2 -mfma vectorises to 256-bit AVX2, one thread per core on an atomic tile queue), "
+                  "(the 8-lane decompression, slab and triangle loops are written so that gcc -O3 -mavx2 -mfma turns each into 256-bit AVX2 "
+                  "code like the reference's f32x8; one thread per core on an atomic tile queue), "
                   "not the Rust reference (no Rust toolchain in this pipeline)",
     }
 

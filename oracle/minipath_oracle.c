@@ -194,7 +194,10 @@ unsigned mpo_tri8_intersect(const float v0[3][8], const float v1[3][8], const fl
                             float t[8], float u[8], float v[8]) {
     const float ox = ray->o[0], oy = ray->o[1], oz = ray->o[2];
     const float dx = ray->d[0], dy = ray->d[1], dz = ray->d[2];
-    unsigned mask = 0;
+    /* results go through locals (no aliasing with the inputs) and the lane mask is assembled after the arithmetic loop, so that
+     * gcc vectorises the loop: 8 lanes = one AVX2 register, as the reference's f32x8 */
+    int m8[L8];
+    float t8[L8], u8[L8], v8[L8];
     for (int i = 0; i < L8; i++) {
         float e1x = v1[0][i] - v0[0][i], e1y = v1[1][i] - v0[1][i], e1z = v1[2][i] - v0[2][i];
         float e2x = v2[0][i] - v0[0][i], e2y = v2[1][i] - v0[1][i], e2z = v2[2][i] - v0[2][i];
@@ -212,10 +215,11 @@ unsigned mpo_tri8_intersect(const float v0[3][8], const float v1[3][8], const fl
         float qz = FMS(sx, e1y, sy * e1x);
         float vv = inv_det * FMA_DOT(dx, dy, dz, qx, qy, qz);     /* :206 */
         float tt = inv_det * FMA_DOT(e2x, e2y, e2z, qx, qy, qz);  /* :207 */
-        int m = (uu >= 0.0f) & (vv >= 0.0f) & ((uu + vv) <= 1.0f); /* :209-211 */
-        mask |= (unsigned)m << i;
-        t[i] = tt; u[i] = uu; v[i] = vv;
+        m8[i] = (uu >= 0.0f) & (vv >= 0.0f) & ((uu + vv) <= 1.0f); /* :209-211 */
+        t8[i] = tt; u8[i] = uu; v8[i] = vv;
     }
+    unsigned mask = 0;
+    for (int i = 0; i < L8; i++) { mask |= (unsigned)m8[i] << i; t[i] = t8[i]; u[i] = u8[i]; v[i] = v8[i]; }
     return mask;
 }
 
@@ -244,6 +248,10 @@ uint16_t mpo_unit_interval_compress(float v, int rounding, int mask) {
 /* RelativePoint8::decompress :95-110 : size.mul_add(relative, min) */
 static inline float decompress_coord(uint16_t q, float size, float min) {
     return fmaf(size, mpo_unit_interval_decompress(q), min);
+}
+/* eight lanes at once (RelativePoint8 / RelativeBox8 decompress): a plain loop gcc turns into vpmovzxwd + vcvtdq2ps + vfmadd */
+static inline void decompress8(const uint16_t *restrict q, float size, float min, float *restrict out) {
+    for (int i = 0; i < L8; i++) out[i] = fmaf(size, (float)(int32_t)q[i] * INV_U16_MAX, min);
 }
 /* RelativePoint8::compress_internal :74-93 : relative = (p - min) / size */
 static inline uint16_t compress_coord(float p, float min, float size, int rounding, int mask) {
@@ -1150,11 +1158,10 @@ static void bvh_intersect_one(const mpo_bvh *b, const mpo_ray *ray, stack_cache 
             const mpo_inner_node *node = &b->inner[index];
             if (cnt) cnt->inner_visited++;
             float bmin[3][8], bmax[3][8], t1[8], t2[8];
-            for (int k = 0; k < 3; k++)
-                for (int i = 0; i < L8; i++) {
-                    bmin[k][i] = decompress_coord(node->bmin[k][i], e.size[k], e.mn[k]);
-                    bmax[k][i] = decompress_coord(node->bmax[k][i], e.size[k], e.mn[k]);
-                }
+            for (int k = 0; k < 3; k++) {
+                decompress8(node->bmin[k], e.size[k], e.mn[k], bmin[k]);
+                decompress8(node->bmax[k], e.size[k], e.mn[k], bmax[k]);
+            }
             mpo_aabb8_intersect(bmin, bmax, ray, best.t, t1, t2);
             for (int i = 0; i < L8; i++) { /* bit_iter ascending :158-161 */
                 if (!(t1[i] <= t2[i])) continue;
@@ -1173,8 +1180,7 @@ static void bvh_intersect_one(const mpo_bvh *b, const mpo_ray *ray, stack_cache 
                 if (cnt) cnt->packets_tested++;
                 float v[3][3][8], t[8], u[8], vv[8];
                 for (int a = 0; a < 3; a++)
-                    for (int k = 0; k < 3; k++)
-                        for (int i = 0; i < L8; i++) v[a][k][i] = decompress_coord(pk->v[a][k][i], e.size[k], e.mn[k]);
+                    for (int k = 0; k < 3; k++) decompress8(pk->v[a][k], e.size[k], e.mn[k], v[a][k]);
                 unsigned mask = mpo_tri8_intersect(v[0], v[1], v[2], ray, t, u, vv);
                 for (int i = 0; i < L8; i++) {
                     if (!((mask >> i) & 1u)) continue;
