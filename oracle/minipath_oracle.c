@@ -166,22 +166,21 @@ static inline float fast_max(float a, float b) { return a > b ? a : b; }
 /* aabb.rs:254-284 */
 void mpo_aabb8_intersect(const float bmin[3][8], const float bmax[3][8], const mpo_ray *ray, float max_t,
                          float t1[8], float t2[8]) {
-    float lo[3][L8], hi[3][L8];
-    for (int k = 0; k < 3; k++) {
-        const float o = ray->o[k], inv = ray->inv[k];
-        for (int i = 0; i < L8; i++) {
-            float a = (bmin[k][i] - o) * inv;
-            a = (a != a) ? -INFINITY : a; /* :262-264 */
-            float b = (bmax[k][i] - o) * inv;
-            b = (b != b) ? INFINITY : b;  /* :265-267 */
-            lo[k][i] = fast_min(a, b);    /* :270 */
-            hi[k][i] = fast_max(a, b);    /* :271 */
-        }
-    }
+    /* one loop over the 8 lanes with local results (no aliasing checks): gcc emits one AVX2 instruction per line, as f32x8 */
+    const float ox = ray->o[0], oy = ray->o[1], oz = ray->o[2];
+    const float ix = ray->inv[0], iy = ray->inv[1], iz = ray->inv[2];
+    float r1[L8], r2[L8];
     for (int i = 0; i < L8; i++) {
-        t1[i] = fast_max(fast_max(lo[0][i], 0.0f), fast_max(lo[1][i], lo[2][i]));   /* :273-276 */
-        t2[i] = fast_min(fast_min(hi[0][i], max_t), fast_min(hi[1][i], hi[2][i])); /* :277-280 */
+        float ax = (bmin[0][i] - ox) * ix, ay = (bmin[1][i] - oy) * iy, az = (bmin[2][i] - oz) * iz;
+        float bx = (bmax[0][i] - ox) * ix, by = (bmax[1][i] - oy) * iy, bz = (bmax[2][i] - oz) * iz;
+        ax = (ax != ax) ? -INFINITY : ax; ay = (ay != ay) ? -INFINITY : ay; az = (az != az) ? -INFINITY : az; /* :262-264 */
+        bx = (bx != bx) ? INFINITY : bx; by = (by != by) ? INFINITY : by; bz = (bz != bz) ? INFINITY : bz;    /* :265-267 */
+        const float lox = fast_min(ax, bx), loy = fast_min(ay, by), loz = fast_min(az, bz); /* :270 */
+        const float hix = fast_max(ax, bx), hiy = fast_max(ay, by), hiz = fast_max(az, bz); /* :271 */
+        r1[i] = fast_max(fast_max(lox, 0.0f), fast_max(loy, loz));   /* :273-276 */
+        r2[i] = fast_min(fast_min(hix, max_t), fast_min(hiy, hiz)); /* :277-280 */
     }
+    for (int i = 0; i < L8; i++) { t1[i] = r1[i]; t2[i] = r2[i]; }
 }
 
 /* util/simba.rs:57-59 */
