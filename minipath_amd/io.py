@@ -1,5 +1,5 @@
 """Image output.  The reference renders into an `image::RgbaImage` and never writes it
-(src/cli.rs:33-46 drops the result); this is the missing last step: RGBA8 PNG and float PFM writers, stdlib only."""
+(src/cli.rs:33-46 drops the result); this is the missing last step: RGBA8 PNG, float PFM and float OpenEXR writers, stdlib + numpy only."""
 from __future__ import annotations
 
 import struct
@@ -61,6 +61,76 @@ def save_pfm(path: str, rgb_f32: np.ndarray) -> None:
 
 # ---- checkpoint / resume of a progressive render (SURVEY "aux subsystems": the reference has none; BASELINE configs[4]) ----
 _CKPT_KEYS = ("tile_size", "sample_count", "width", "height", "seed", "max_depth", "chunked_sum")
+
+
+def save_exr(path: str, rgba_f32: np.ndarray) -> None:
+    """Write the f32 means (RenderProgress.image_f32(), [h, w, 4] or [h, w, 3]) as an uncompressed 32-bit-float scanline
+    OpenEXR file (version 2, single part, channels A/B/G/R or B/G/R, INCREASING_Y): the values survive bit for bit."""
+    img = np.ascontiguousarray(rgba_f32, dtype="<f4")
+    if img.ndim != 3 or img.shape[2] not in (3, 4):
+        raise ValueError("expected an [h, w, 3|4] float image")
+    h, w, nc = img.shape
+    names = ["A", "B", "G", "R"] if nc == 4 else ["B", "G", "R"]  # channels are stored in alphabetical order
+    plane = {"R": 0, "G": 1, "B": 2, "A": 3}
+
+    def attr(name: str, typ: str, value: bytes) -> bytes:
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(value)) + value
+
+    chlist = b"".join(n.encode() + b"\0" + struct.pack("<iB3xii", 2, 0, 1, 1) for n in names) + b"\0"  # 2 = FLOAT
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    header = (struct.pack("<ii", 20000630, 2)
+              + attr("channels", "chlist", chlist)
+              + attr("compression", "compression", b"\0")
+              + attr("dataWindow", "box2i", box)
+              + attr("displayWindow", "box2i", box)
+              + attr("lineOrder", "lineOrder", b"\0")
+              + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+              + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0))
+              + attr("screenWindowWidth", "float", struct.pack("<f", 1.0))
+              + b"\0")
+    row_bytes = 8 + len(names) * w * 4
+    first = len(header) + 8 * h
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(np.arange(h, dtype="<u8").__mul__(row_bytes).__add__(first).tobytes())  # scanline offset table
+        for y in range(h):
+            f.write(struct.pack("<ii", y, len(names) * w * 4))
+            for n in names:
+                f.write(img[y, :, plane[n]].tobytes())
+
+
+def load_exr_f32(path: str) -> np.ndarray:
+    """Reader for the files save_exr writes (uncompressed FLOAT scanlines): round-trip tests.  Returns [h, w, channels] in
+    R, G, B(, A) order."""
+    data = open(path, "rb").read()
+    if struct.unpack("<i", data[:4])[0] != 20000630:
+        raise ValueError("not an OpenEXR file")
+    pos, attrs = 8, {}
+    while data[pos] != 0:
+        e = data.index(b"\0", pos); name = data[pos:e].decode(); pos = e + 1
+        e = data.index(b"\0", pos); pos = e + 1
+        (n,) = struct.unpack("<i", data[pos:pos + 4]); pos += 4
+        attrs[name] = data[pos:pos + n]; pos += n
+    pos += 1
+    if attrs["compression"] != b"\0":
+        raise ValueError("only uncompressed files")
+    x0, y0, x1, y1 = struct.unpack("<iiii", attrs["dataWindow"])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    names, c = [], attrs["channels"]
+    q = 0
+    while c[q] != 0:
+        e = c.index(b"\0", q); names.append(c[q:e].decode())
+        if struct.unpack("<i", c[e + 1:e + 5])[0] != 2:
+            raise ValueError("only FLOAT channels")
+        q = e + 17
+    offs = np.frombuffer(data, "<u8", h, pos)
+    out = np.zeros((h, w, len(names)), np.float32)
+    order = {"R": 0, "G": 1, "B": 2, "A": 3}
+    for y in range(h):
+        o = int(offs[y]) + 8
+        for k, n in enumerate(names):
+            out[y, :, order[n]] = np.frombuffer(data, "<f4", w, o + k * w * 4)
+    return out
 
 
 def _settings_key(settings) -> np.ndarray:
