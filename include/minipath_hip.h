@@ -168,7 +168,7 @@ typedef struct {
     float *d_normal;        /* n*3, HitRecord.normal  (optional) */
     float *d_tex;           /* n*3, HitRecord.texture_coords (optional) */
     uint32_t *d_material;   /* HitRecord.material (geometry/mod.rs:78), 0 on miss (optional) */
-    uint32_t *d_instance;   /* mp_scene_instances only: index of the instance that was hit, 0 otherwise (optional) */
+    uint32_t *d_instance;   /* object groups (mp_scene_group / mp_scene_instances): index of the member that was hit, 0 otherwise (optional) */
 } mp_hits_soa;
 
 typedef void (*mp_tile_started_cb)(void *user, mp_block tile);                       /* F1, machinery.rs:22 */
@@ -225,13 +225,20 @@ int mp_scene_set_materials(mp_scene *scene, const mp_material *table, uint32_t n
 const char *mp_scene_material_name(const mp_scene *scene, uint32_t id);
 /* scene/primitives.rs:10-56 Sphere as the scene's Object (analytic intersection, no BVH).  ctx may be NULL (host-only). */
 int mp_scene_sphere(mp_ctx *ctx, const float center[3], float radius, mp_scene **out);
-/* BUILD-DEFINED Object (scene/mod.rs:7-10 `trait Object`; the reference's Scene holds ONE object and has no transforms): n
- * instances {object, translation} of one TriangleBvh scene (translations: n*3 floats, copied).  intersect = for every instance in
- * order the object's own intersect with the ray moved into the instance's frame (origin - translation; direction and t
- * unchanged), closest wins with a strict `<` (the first instance keeps ties); HitRecord.point = point_at(t) of the world ray,
- * normal / tex / material are the object's.  The new scene SHARES the object's device arrays: `object` must outlive it.
- * Rendered by the 8-lane-group traversal (every kernel but the staged MP_FLAG_WAVEFRONT pipeline); defined operation by
- * operation in oracle/minipath_oracle.c (bvh_intersect_impl). */
+/* BUILD-DEFINED Object (scene/mod.rs:7-10 `trait Object`; the reference's Scene holds ONE object and has no transforms): a
+ * top-level list of n members {object, translation} (objects: n TriangleBvh scenes of this context, repeats allowed;
+ * translations: n*3 floats, copied).  intersect = for every member in order the member's own intersect with the ray moved into
+ * the member's frame (origin - translation; direction and t unchanged), closest wins with a strict `<` (the first member keeps
+ * ties); HitRecord.point = point_at(t) of the world ray, normal / tex / material id are the member's; mp_hits_soa.d_instance =
+ * index of the member that was hit, prim = triangle index inside that member.  The group has ONE material table indexed by the
+ * members' material ids (initially the first member's, padded with the default material; mp_scene_set_materials replaces it)
+ * and the first member's sky radiance.  get_bounding_box = union of the translated boxes; mp_scene_info counts are sums over the
+ * members.  The group SHARES its members' device arrays: they must outlive it.  Rendered by the 8-lane-group traversal (every
+ * kernel but the staged MP_FLAG_WAVEFRONT pipeline); defined operation by operation in oracle/minipath_oracle.c
+ * (bvh_intersect_impl). */
+int mp_scene_group(mp_ctx *ctx, const mp_scene *const *objects, const float *translations, uint32_t n, mp_scene **out);
+/* n members that are all `object` (instancing): as mp_scene_group, except that mp_scene_info reports the object's own counts and
+ * mp_scene_export exports the object's arrays. */
 int mp_scene_instances(mp_ctx *ctx, const mp_scene *object, const float *translations, uint32_t n, mp_scene **out);
 void mp_scene_destroy(mp_scene *scene);
 int mp_scene_info_get(const mp_scene *scene, mp_scene_info *out);

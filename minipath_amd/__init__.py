@@ -7,12 +7,12 @@ All compute happens in ``csrc/libminipath_hip.so`` (hand-written HIP kernels); t
 from ._lib import MinipathError, MP_NO_PRIM, MP_LINK_NULL, SO_PATH  # noqa: F401
 from .camera import Camera, CameraSampler  # noqa: F401
 from .screen_block import ScreenBlock, tile_ordering  # noqa: F401
-from .scene import Context, Instances, Scene, Sphere, TriangleBvh  # noqa: F401
+from .scene import Context, Instances, ObjectGroup, Scene, Sphere, TriangleBvh  # noqa: F401
 from .renderer import (RenderProgress, RenderProgressSnapshot, RenderSettings, render, render_multi, render_tile,  # noqa: F401
                        FrameRenderer, MultiDeviceFrame)
 
 __all__ = [
-    "Camera", "CameraSampler", "Context", "Instances", "FrameRenderer", "MinipathError", "MultiDeviceFrame", "RenderProgress", "render_multi",
+    "Camera", "CameraSampler", "Context", "Instances", "FrameRenderer", "MinipathError", "MultiDeviceFrame", "ObjectGroup", "RenderProgress", "render_multi",
     "RenderProgressSnapshot", "RenderSettings", "Scene", "ScreenBlock", "Sphere", "TriangleBvh", "render", "render_tile",
     "tile_ordering",
 ]

@@ -171,8 +171,10 @@ struct mp_scene {
         }
     };
     std::shared_ptr<DevTable> mat_table;
-    void* d_inst = nullptr;               // mp_scene_instances: translations
-    const mp_scene* inst_of = nullptr;    // ... of this object, whose device arrays this scene borrows
+    void* d_inst = nullptr;               // object group (mp_scene_group / mp_scene_instances): DevObject per member
+    const mp_scene* inst_of = nullptr;    // ... first member; the group borrows its members' device arrays
+    std::vector<const mp_scene*> members;
+    bool one_object = false;              // mp_scene_instances: every member is inst_of
     std::vector<float> inst_t;
     std::vector<mp_material> materials{mp_material{0.75f, 0.0f}};  // build-defined path extension defaults
     float sky = 1.0f;
@@ -724,47 +726,96 @@ int mp_scene_from_arrays(mp_ctx* ctx, const mp_bvh_desc* desc, mp_scene** out) {
     });
 }
 
-int mp_scene_instances(mp_ctx* ctx, const mp_scene* object, const float* translations, uint32_t n, mp_scene** out) {
-    return guarded([&]() -> int {
-    if (!object || !translations || !out || n == 0) return fail(MP_ERR_INVALID, "bad argument");
-    if (object->dev.kind != 0u || object->inst_of) return fail(MP_ERR_UNSUPPORTED, "instances are made of a TriangleBvh scene");
-    if (object->ctx != ctx) return fail(MP_ERR_INVALID, "object belongs to another context");
-    if (n > (1u << 20)) return fail(MP_ERR_INVALID, "too many instances");
+namespace {
+
+// {object, translation} x n behind one Object (include/minipath_hip.h: mp_scene_group).  The group borrows its members' device
+// arrays; it owns the descriptor array and its own material table.
+int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* translations, uint32_t n, bool one_object, mp_scene** out) {
+    if (!objects || !translations || !out || n == 0) return fail(MP_ERR_INVALID, "bad argument");
+    if (n > (1u << 20)) return fail(MP_ERR_INVALID, "too many members");
+    for (uint32_t i = 0; i < n; i++) {
+        const mp_scene* o = objects[i];
+        if (!o) return fail(MP_ERR_INVALID, "NULL member");
+        if (o->dev.kind != 0u || o->inst_of) return fail(MP_ERR_UNSUPPORTED, "the members of an object group are TriangleBvh scenes");
+        if (o->ctx != ctx) return fail(MP_ERR_INVALID, "member belongs to another context");
+    }
     auto s = std::make_unique<mp_scene>();
     s->ctx = ctx;
-    s->inst_of = object;
+    s->inst_of = objects[0];
+    s->one_object = one_object;
+    s->members.assign(objects, objects + n);
     s->inst_t.assign(translations, translations + static_cast<size_t>(n) * 3);
-    s->host.root = object->host.root;
-    s->host.depth = object->host.depth;
-    s->host.vertex_count = object->host.vertex_count;
-    s->host.triangle_count = object->host.triangle_count;
-    s->host.material_names = object->host.material_names;
+    s->host.root = objects[0]->host.root;
+    s->host.material_names = objects[0]->host.material_names;
+    s->material_count = 1;
+    s->dev = objects[0]->dev;
+    for (uint32_t i = 0; i < n; i++) {
+        const mp_scene* o = objects[i];
+        s->host.depth = std::max(s->host.depth, o->host.depth);
+        if (!one_object || i == 0) {  // instances of one object report the object's own counts
+            s->host.vertex_count += o->host.vertex_count;
+            s->host.triangle_count += o->host.triangle_count;
+        }
+        s->material_count = std::max(s->material_count, o->material_count);
+        s->dev.stack_cap = std::max(s->dev.stack_cap, o->dev.stack_cap);
+    }
     for (int k = 0; k < 3; k++) {  // get_bounding_box: union of the translated boxes
         float mn = 0, mx = 0;
         for (uint32_t i = 0; i < n; i++) {
-            const float a = object->host.bbox.mn[k] + translations[3 * i + k], b = object->host.bbox.mx[k] + translations[3 * i + k];
+            const float a = objects[i]->host.bbox.mn[k] + translations[3 * i + k], b = objects[i]->host.bbox.mx[k] + translations[3 * i + k];
             mn = i ? std::fmin(mn, a) : a;
             mx = i ? std::fmax(mx, b) : b;
         }
         s->host.bbox.mn[k] = mn;
         s->host.bbox.mx[k] = mx;
     }
-    s->materials = object->materials;
-    s->sky = object->sky;
-    s->material_count = object->material_count;
-    s->dev = object->dev;
-    s->mat_table = object->mat_table;  // a snapshot: a later mp_scene_set_materials on `object` does not reach this scene
+    // material table of the group: the first member's, padded with the default material up to the largest id any member uses
+    s->materials = objects[0]->materials;
+    if (s->materials.size() < s->material_count) s->materials.resize(s->material_count, mp_material{0.75f, 0.0f});
+    s->sky = objects[0]->sky;
+    s->mat_table = objects[0]->mat_table;  // a snapshot: a later mp_scene_set_materials on the member does not reach the group
     s->dev.inst_count = n;
+    s->dev.has_pre = 0;
     if (ctx) {
         DeviceGuard g(ctx->device);
-        MP_HIP(hipMalloc(&s->d_inst, static_cast<size_t>(n) * 12));
-        hipError_t e = hipMemcpy(s->d_inst, translations, static_cast<size_t>(n) * 12, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(s->d_inst); return hip_fail(e, "hipMemcpy(instances)"); }
-        s->dev.inst_t = static_cast<const float*>(s->d_inst);
-        s->device_bytes = static_cast<uint64_t>(n) * 12;
+        std::vector<DevObject> desc(n);
+        for (uint32_t i = 0; i < n; i++) {
+            const DevScene& d = objects[i]->dev;
+            DevObject& o = desc[i];
+            std::memset(&o, 0, sizeof(o));
+            o.shade = d.shade; o.nodes_aos = d.nodes_aos; o.tris_aos = d.tris_aos; o.vidx = d.vidx; o.vtex = d.vtex;
+            o.root = d.root; o.has_pre = d.has_pre;
+            for (int k = 0; k < 3; k++) { o.pre_min[k] = d.pre_min[k]; o.pre_max[k] = d.pre_max[k]; o.t[k] = translations[3 * i + k]; }
+        }
+        MP_HIP(hipMalloc(&s->d_inst, desc.size() * sizeof(DevObject)));
+        hipError_t e = hipMemcpy(s->d_inst, desc.data(), desc.size() * sizeof(DevObject), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(s->d_inst); return hip_fail(e, "hipMemcpy(object group)"); }
+        s->dev.objects = static_cast<const DevObject*>(s->d_inst);
+        s->device_bytes = desc.size() * sizeof(DevObject);
+        if (s->materials.size() != objects[0]->materials.size()) {  // padded table: the group needs its own device copy
+            auto tb = std::make_shared<mp_scene::DevTable>();
+            tb->device = ctx->device;
+            MP_HIP(hipMalloc(&tb->d, std::max<size_t>(16, s->materials.size() * sizeof(mp_material))));
+            MP_HIP(hipMemcpy(tb->d, s->materials.data(), s->materials.size() * sizeof(mp_material), hipMemcpyHostToDevice));
+            s->mat_table = std::move(tb);
+            s->dev.materials = static_cast<const float*>(s->mat_table->d);
+        }
     }
     *out = s.release();
     return MP_OK;
+}
+
+}  // namespace
+
+int mp_scene_group(mp_ctx* ctx, const mp_scene* const* objects, const float* translations, uint32_t n, mp_scene** out) {
+    return guarded([&]() -> int { return make_group(ctx, objects, translations, n, false, out); });
+}
+
+int mp_scene_instances(mp_ctx* ctx, const mp_scene* object, const float* translations, uint32_t n, mp_scene** out) {
+    return guarded([&]() -> int {
+    if (!object || n == 0 || n > (1u << 20)) return fail(MP_ERR_INVALID, "bad argument");
+    std::vector<const mp_scene*> objs(n, object);
+    return make_group(ctx, objs.data(), translations, n, true, out);
     });
 }
 
@@ -829,8 +880,17 @@ int mp_scene_info_get(const mp_scene* s, mp_scene_info* out) {
     return guarded([&]() -> int {
     if (!s || !out) return fail(MP_ERR_INVALID, "NULL argument");
     out->root_link = s->host.root;
-    out->inner_count = static_cast<uint32_t>((s->inst_of ? s->inst_of->host : s->host).inner.size());
-    out->packet_count = static_cast<uint32_t>((s->inst_of ? s->inst_of->host : s->host).packets.size());
+    out->inner_count = static_cast<uint32_t>(s->host.inner.size());
+    out->packet_count = static_cast<uint32_t>(s->host.packets.size());
+    if (s->inst_of) {  // object group: sums over the members (instances of one object: the object's own counts)
+        uint64_t ni = 0, np = 0;
+        for (size_t i = 0; i < (s->one_object ? 1 : s->members.size()); i++) {
+            ni += s->members[i]->host.inner.size();
+            np += s->members[i]->host.packets.size();
+        }
+        out->inner_count = static_cast<uint32_t>(ni);
+        out->packet_count = static_cast<uint32_t>(np);
+    }
     out->vertex_count = s->host.vertex_count;
     out->triangle_count = s->host.triangle_count;
     out->depth = s->host.depth;
@@ -850,6 +910,7 @@ int mp_scene_export(const mp_scene* s, void* inner_nodes, void* packets, void* t
                     float* vertex_tex, uint32_t* tri_material) {
     return guarded([&]() -> int {
     if (!s) return fail(MP_ERR_INVALID, "scene is NULL");
+    if (s->inst_of && !s->one_object) return fail(MP_ERR_UNSUPPORTED, "an object group has no arrays of its own: export its members");
     const HostBvh& h = s->inst_of ? s->inst_of->host : s->host;
     if (inner_nodes && !h.inner.empty()) std::memcpy(inner_nodes, h.inner.data(), h.inner.size() * sizeof(InnerNodeRef));
     if (packets && !h.packets.empty()) std::memcpy(packets, h.packets.data(), h.packets.size() * sizeof(TriPacketRef));

@@ -172,7 +172,9 @@ __device__ __forceinline__ uint64_t mask_ge(float a, float b) { return __builtin
 // Traces `nrays` rays held in the wave's LDS queue `q` (rows ox,oy,oz,dx,dy,dz; slot = column).
 // On return rows 0..3 of each slot hold the closest hit: t (f32::MAX on miss), prim (bits), u, v.
 // impl Object for TriangleBvh::intersect, ray_bvh_intersection.rs:26-96, for 8 rays at a time.
-template <bool PATCH_NAN>
+// BFE: the count of passing children below a lane from v_bfe_u32 instead of a loop-invariant mask register (one VGPR less, one
+// VALU more per node step): pays in trace_rays_kernel, which sits at the 64-VGPR cap, and costs 0.5 % in render_paths_kernel.
+template <bool PATCH_NAN, bool BFE>
 __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __restrict__ q, uint2* __restrict__ stack_base,
                                                 int nrays) {
     const int lane = static_cast<int>(threadIdx.x) & 63;
@@ -273,7 +275,8 @@ __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __res
                     const uint64_t okm = mask_le(t1, t2) & __builtin_amdgcn_uicmp(child, MP_LINK_NULL, 33);  // 33 = ICMP_NE
                     const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
                     uint32_t m = static_cast<uint32_t>(okm >> (g * 8)) & 0xFFu;
-                    if (ok) stack[sp + __popc(m & lanes_below)] = make_uint2(child, as_u(t1));  // ascending lane :161
+                    const uint32_t below = BFE ? __builtin_amdgcn_ubfe(m, 0u, static_cast<uint32_t>(li)) : (m & lanes_below);
+                    if (ok) stack[sp + __popc(below)] = make_uint2(child, as_u(t1));  // ascending lane :161
                     sp += __popc(m);
                 } else {
                     pk = link >> 6;  // Leaf :56-62 ; device link = first packet << 6 | real triangles
@@ -306,11 +309,12 @@ __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __res
 
 // A queue without a ray that has a zero direction component cannot produce 0 * inf in the slab test: it runs the variant
 // without the NaN patches (six VALU per node step less).  Wave-uniform choice per call.
+template <bool BFE = false>
 __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict__ q, uint2* __restrict__ stack_base, int nrays) {
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const bool zero = lane < nrays && (q[3 * 64 + lane] == 0.0f || q[4 * 64 + lane] == 0.0f || q[5 * 64 + lane] == 0.0f);
-    if (__ballot(zero) != 0) trace_wave_impl<true>(sc, q, stack_base, nrays);
-    else trace_wave_impl<false>(sc, q, stack_base, nrays);
+    if (__ballot(zero) != 0) trace_wave_impl<true, BFE>(sc, q, stack_base, nrays);
+    else trace_wave_impl<false, BFE>(sc, q, stack_base, nrays);
 }
 
 // Exact conservative pre-test against the union of the root node's child boxes (DevScene::pre_min/pre_max): every
@@ -330,11 +334,62 @@ __device__ __forceinline__ bool may_hit_scene(const DevScene& sc, const Ray& r) 
     return t1 <= t2;
 }
 
-// Build-defined instanced Object (mp_scene_instances): the ray in instance k's frame (origin - translation; direction unchanged).
-__device__ __forceinline__ void instance_ray(const DevScene& sc, uint32_t k, const Ray& r, Ray& rk) {
+// Build-defined object group (mp_scene_group / mp_scene_instances): the scene seen as member k -- the member's own traversal
+// arrays under the group's material table and stack bound.  k is wave-uniform in the pass over member k (scalar loads) and per
+// lane when a lane shades the member its ray hit.
+__device__ __forceinline__ void object_scene(const DevScene& sc, uint32_t k, DevScene& sk) {
+    sk = sc;
+    const DevObject& o = sc.objects[k];
+    sk.shade = o.shade; sk.nodes_aos = o.nodes_aos; sk.tris_aos = o.tris_aos; sk.vidx = o.vidx; sk.vtex = o.vtex;
+    sk.root = o.root; sk.has_pre = o.has_pre;
+    for (int i = 0; i < 3; i++) { sk.pre_min[i] = o.pre_min[i]; sk.pre_max[i] = o.pre_max[i]; }
+}
+// ... and the ray in member k's frame (origin - translation; direction, hence t, unchanged)
+__device__ __forceinline__ void object_ray(const DevScene& sc, uint32_t k, const Ray& r, Ray& rk) {
+    const float* t = sc.objects[k].t;
     rk = r;
-    if (sc.inst_count) {
-        rk.ox = r.ox - sc.inst_t[3 * k]; rk.oy = r.oy - sc.inst_t[3 * k + 1]; rk.oz = r.oz - sc.inst_t[3 * k + 2];
+    rk.ox = r.ox - t[0]; rk.oy = r.oy - t[1]; rk.oz = r.oz - t[2];
+}
+
+struct GroupHit {
+    float t, u, v;
+    uint32_t prim, inst;
+};
+
+// Closest hit of the wave's rays (one per lane, `act` = lane holds a ray) with the group walk: compaction of the lanes whose ray
+// can reach the object into the wave's ray queue, trace_wave, results back to the lanes.  OBJ: once per member of the object
+// group, in order, closest wins with a strict `<` (the first member keeps ties).
+template <bool OBJ, bool BFE = false>
+__device__ __forceinline__ void trace_objects(const DevScene& sc, const Ray& r, bool act, float* __restrict__ q,
+                                              uint2* __restrict__ stack, uint64_t lanes_lt, GroupHit& h) {
+    h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim; h.inst = 0u;
+    auto pass = [&](const DevScene& sk, const Ray& rk, uint32_t k) {
+        const bool queued = act && may_hit_scene(sk, rk);
+        const uint64_t am = __ballot(queued);
+        const int n = __popcll(am), rank = __popcll(am & lanes_lt);
+        if (queued) {
+            q[0 * 64 + rank] = rk.ox; q[1 * 64 + rank] = rk.oy; q[2 * 64 + rank] = rk.oz;
+            q[3 * 64 + rank] = rk.dx; q[4 * 64 + rank] = rk.dy; q[5 * 64 + rank] = rk.dz;
+        }
+        wave_lds_sync();
+        trace_wave<BFE>(sk, q, stack, n);
+        if (queued) {
+            const uint32_t prim = as_u(q[1 * 64 + rank]);
+            const float t = q[0 * 64 + rank];
+            if (prim != kNoPrim && t < h.t) { h.t = t; h.prim = prim; h.u = q[2 * 64 + rank]; h.v = q[3 * 64 + rank]; h.inst = k; }
+        }
+        wave_lds_sync();
+    };
+    if (!OBJ) {
+        pass(sc, r, 0u);
+        return;
+    }
+    for (uint32_t k = 0; k < sc.inst_count; k++) {
+        DevScene sk;
+        Ray rk;
+        object_scene(sc, k, sk);
+        object_ray(sc, k, r, rk);
+        pass(sk, rk, k);
     }
 }
 
@@ -467,7 +522,7 @@ __device__ __forceinline__ void pixel_state_store(const RenderParams& P, size_t 
     }
 
 // S = samples of one pixel in flight in a wavefront (64/S pixels x S consecutive samples per pass).
-template <int S>
+template <int S, bool OBJ>
 __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int BW = (S == 1) ? 8 : (S == 2) ? 8 : (S == 4) ? 4 : 4;
@@ -514,34 +569,19 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
                 if (P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) chunk_flush(P, off, inpix && sub == 0, acc);
                 continue;
             }
-            // per object instance (one pass for a plain TriangleBvh): compaction of the lanes whose ray can reach the object into
-            // the wave's ray queue, group traversal, closest hit over the instances with a strict `<`
-            float bt = FLT_MAX, bu = 0.0f, bv = 0.0f;
-            uint32_t bprim = kNoPrim;
-            const uint32_t ninst = P.scene.inst_count ? P.scene.inst_count : 1u;
-            for (uint32_t k = 0; k < ninst; k++) {
-                Ray rk;
-                instance_ray(P.scene, k, r, rk);
-                const bool queued = act && may_hit_scene(P.scene, rk);
-                const uint64_t am = __ballot(queued);
-                const int n = __popcll(am), rank = __popcll(am & lanes_lt);
-                if (queued) {
-                    q[0 * 64 + rank] = rk.ox; q[1 * 64 + rank] = rk.oy; q[2 * 64 + rank] = rk.oz;
-                    q[3 * 64 + rank] = rk.dx; q[4 * 64 + rank] = rk.dy; q[5 * 64 + rank] = rk.dz;
-                }
-                wave_lds_sync();
-                trace_wave(P.scene, q, stack, n);
-                if (queued) {
-                    const uint32_t prim = as_u(q[1 * 64 + rank]);
-                    const float t = q[0 * 64 + rank];
-                    if (prim != kNoPrim && t < bt) { bt = t; bprim = prim; bu = q[2 * 64 + rank]; bv = q[3 * 64 + rank]; }
-                }
-                wave_lds_sync();
-            }
+            // group walk (once per member of an object group): closest hit, then the shading of worker.rs:59-65
+            GroupHit gh;
+            trace_objects<OBJ>(P.scene, r, act, q, stack, lanes_lt, gh);
             float c = 0.0f, h = 0.0f;
-            if (bprim != kNoPrim) {
+            if (gh.prim != kNoPrim) {
                 float nn[3];
-                resolve_normal(P.scene, bprim, bu, bv, nn);
+                if (OBJ) {
+                    DevScene so;
+                    object_scene(P.scene, gh.inst, so);
+                    resolve_normal(so, gh.prim, gh.u, gh.v, nn);
+                } else {
+                    resolve_normal(P.scene, gh.prim, gh.u, gh.v, nn);
+                }
                 c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60
                 h = 1.0f;
             }
@@ -1226,7 +1266,7 @@ __device__ __forceinline__ bool path_vertex(const DevScene& sc, const PacketHit&
     return true;
 }
 
-template <int S>
+template <int S, bool OBJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void render_paths_kernel(RenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : 2;
@@ -1275,7 +1315,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 if (alive_m == 0) break;
                 segs += static_cast<unsigned long long>(__popcll(alive_m));
                 h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
-                if (depth == 1 && P.scene.inst_count == 0u) {
+                uint32_t hinst = 0u;
+                if (depth == 1 && !OBJ) {
                     const bool go = alive && may_hit_scene(P.scene, r);
                     if (__ballot(go) != 0) {
                         RegStack rst(nullptr, lane);
@@ -1284,29 +1325,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                         else trace_packet<(S >= 8)>(P.scene, r, go, rst, h);
                     }
                 } else {
-                    // bounce rays (and every ray of an instanced object): 8-lane-group traversal, once per object instance
-                    const uint32_t ninst = P.scene.inst_count ? P.scene.inst_count : 1u;
-                    for (uint32_t k = 0; k < ninst; k++) {
-                        Ray rk;
-                        instance_ray(P.scene, k, r, rk);
-                        const bool go = alive && may_hit_scene(P.scene, rk);
-                        const uint64_t gm = __ballot(go);
-                        const int n = __popcll(gm), rank = __popcll(gm & lanes_lt);
-                        if (go) {
-                            q[0 * 64 + rank] = rk.ox; q[1 * 64 + rank] = rk.oy; q[2 * 64 + rank] = rk.oz;
-                            q[3 * 64 + rank] = rk.dx; q[4 * 64 + rank] = rk.dy; q[5 * 64 + rank] = rk.dz;
-                        }
-                        wave_lds_sync();
-                        trace_wave(P.scene, q, stack, n);
-                        if (go) {
-                            const uint32_t prim = as_u(q[1 * 64 + rank]);
-                            const float t = q[0 * 64 + rank];
-                            if (prim != kNoPrim && t < h.t) { h.t = t; h.prim = prim; h.u = q[2 * 64 + rank]; h.v = q[3 * 64 + rank]; }
-                        }
-                        wave_lds_sync();
+                    // bounce rays (and every ray of an object group): group walk, once per member
+                    GroupHit gh;
+                    trace_objects<OBJ>(P.scene, r, alive, q, stack, lanes_lt, gh);
+                    h.t = gh.t; h.u = gh.u; h.v = gh.v; h.prim = gh.prim;
+                    hinst = gh.inst;
+                }
+                if (alive) {
+                    if (OBJ) {
+                        DevScene so = P.scene;
+                        if (h.prim != kNoPrim) object_scene(P.scene, hinst, so);
+                        alive = path_vertex(so, h, depth, P.max_depth, rng, r, L, thr, primary_hit);
+                    } else {
+                        alive = path_vertex(P.scene, h, depth, P.max_depth, rng, r, L, thr, primary_hit);
                     }
                 }
-                if (alive) alive = path_vertex(P.scene, h, depth, P.max_depth, rng, r, L, thr, primary_hit);
             }
             cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
             add_samples_in_order<S>(acc, L, lane);
@@ -1603,6 +1636,7 @@ struct TraceParams {
     uint32_t lds_per_wave;
 };
 
+template <bool OBJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void trace_rays_kernel(TraceParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
@@ -1637,28 +1671,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
             continue;
         }
-        float t = FLT_MAX, u = 0.0f, v = 0.0f;
-        uint32_t prim = kNoPrim, inst = 0u;
-        const uint32_t ninst = P.scene.inst_count ? P.scene.inst_count : 1u;
-        for (uint32_t k = 0; k < ninst; k++) {  // one pass per object instance (one for a plain TriangleBvh)
-            Ray rk;
-            instance_ray(P.scene, k, r0, rk);
-            const bool queued = act && may_hit_scene(P.scene, rk);
-            const uint64_t am = __ballot(queued);
-            const int n = __popcll(am), rank = __popcll(am & ((1ull << lane) - 1ull));
-            if (queued) {
-                q[0 * 64 + rank] = rk.ox; q[1 * 64 + rank] = rk.oy; q[2 * 64 + rank] = rk.oz;
-                q[3 * 64 + rank] = rk.dx; q[4 * 64 + rank] = rk.dy; q[5 * 64 + rank] = rk.dz;
-            }
-            wave_lds_sync();
-            trace_wave(P.scene, q, stack, n);
-            if (queued) {
-                const uint32_t pk = as_u(q[1 * 64 + rank]);
-                const float tk = q[0 * 64 + rank];
-                if (pk != kNoPrim && tk < t) { t = tk; prim = pk; u = q[2 * 64 + rank]; v = q[3 * 64 + rank]; inst = k; }
-            }
-            wave_lds_sync();
-        }
+        GroupHit gh;
+        trace_objects<OBJ, true>(P.scene, r0, act, q, stack, (1ull << lane) - 1ull, gh);
+        const float t = gh.t, u = gh.u, v = gh.v;
+        const uint32_t prim = gh.prim, inst = gh.inst;
         if (act) {
             if (P.hits.d_t) P.hits.d_t[i] = t;
             if (P.hits.d_prim) P.hits.d_prim[i] = prim;
@@ -1668,13 +1684,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 float pt[3] = {0, 0, 0}, nn[3] = {0, 0, 0}, tx[3] = {0, 0, 0};
                 uint32_t mat = 0;  // HitRecord.material (geometry/mod.rs:78)
                 if (prim != kNoPrim) {
-                    mat = resolve_normal(P.scene, prim, u, v, nn);
+                    DevScene so = P.scene;  // the member the ray hit (its normals, texture coordinates, material ids)
+                    if (OBJ) object_scene(P.scene, inst, so);
+                    mat = resolve_normal(so, prim, u, v, nn);
                     Ray r;  // rebuilt here so that no ray registers stay live across the walk
                     ray_new(P.ox[i], P.oy[i], P.oz[i], P.dx[i], P.dy[i], P.dz[i], r);
                     pt[0] = r.ox + r.dx * t; pt[1] = r.oy + r.dy * t; pt[2] = r.oz + r.dz * t;  // geometry/mod.rs:56-58
-                    const uint32_t* vi = P.scene.vidx + static_cast<size_t>(prim) * 3;
-                    const float *t0 = P.scene.vtex + 3 * static_cast<size_t>(vi[0]), *t1 = P.scene.vtex + 3 * static_cast<size_t>(vi[1]),
-                                *t2 = P.scene.vtex + 3 * static_cast<size_t>(vi[2]);
+                    const uint32_t* vi = so.vidx + static_cast<size_t>(prim) * 3;
+                    const float *t0 = so.vtex + 3 * static_cast<size_t>(vi[0]), *t1 = so.vtex + 3 * static_cast<size_t>(vi[1]),
+                                *t2 = so.vtex + 3 * static_cast<size_t>(vi[2]);
                     float w = 1.0f - u - v;
                     for (int k = 0; k < 3; k++) tx[k] = t0[k] * w + t1[k] * u + t2[k] * v;
                 }
@@ -1818,15 +1836,21 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         const uint32_t nspp = L.pass_end - L.pass_begin;  // samples per pixel in this launch
         const int S = nspp >= 8 ? 8 : nspp >= 4 ? 4 : nspp >= 2 ? 2 : 1;  // 16 in flight measured slower here (teapot depth 8: 17.1 vs 15.7 ms)
         const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want * S, static_cast<uint64_t>(L.cu_count) * per_cu));
-        if (S == 8) hipLaunchKernelGGL(render_paths_kernel<8>, dim3(grid), dim3(256), lds, st, P);
-        else if (S == 4) hipLaunchKernelGGL(render_paths_kernel<4>, dim3(grid), dim3(256), lds, st, P);
-        else if (S == 2) hipLaunchKernelGGL(render_paths_kernel<2>, dim3(grid), dim3(256), lds, st, P);
-        else hipLaunchKernelGGL(render_paths_kernel<1>, dim3(grid), dim3(256), lds, st, P);
+        if (L.scene.inst_count != 0u) {  // object group: every segment is walked member by member
+            if (S == 8) hipLaunchKernelGGL((render_paths_kernel<8, true>), dim3(grid), dim3(256), lds, st, P);
+            else if (S == 4) hipLaunchKernelGGL((render_paths_kernel<4, true>), dim3(grid), dim3(256), lds, st, P);
+            else if (S == 2) hipLaunchKernelGGL((render_paths_kernel<2, true>), dim3(grid), dim3(256), lds, st, P);
+            else hipLaunchKernelGGL((render_paths_kernel<1, true>), dim3(grid), dim3(256), lds, st, P);
+        } else if (S == 8) hipLaunchKernelGGL((render_paths_kernel<8, false>), dim3(grid), dim3(256), lds, st, P);
+        else if (S == 4) hipLaunchKernelGGL((render_paths_kernel<4, false>), dim3(grid), dim3(256), lds, st, P);
+        else if (S == 2) hipLaunchKernelGGL((render_paths_kernel<2, false>), dim3(grid), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((render_paths_kernel<1, false>), dim3(grid), dim3(256), lds, st, P);
         return check(hipGetLastError(), "render_paths_kernel launch", err);
     }
-    if (L.traversal == 1 || L.scene.inst_count != 0u) {  // instanced objects are walked per instance by the 8-lane groups
+    if (L.traversal == 1 || L.scene.inst_count != 0u) {  // object groups are walked member by member by the 8-lane groups
         const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * 8));
-        hipLaunchKernelGGL(render_tiles_kernel<1>, dim3(grid), dim3(256), lds, st, P);
+        if (L.scene.inst_count != 0u) hipLaunchKernelGGL((render_tiles_kernel<1, true>), dim3(grid), dim3(256), lds, st, P);
+        else hipLaunchKernelGGL((render_tiles_kernel<1, false>), dim3(grid), dim3(256), lds, st, P);
         return check(hipGetLastError(), "render_tiles_kernel launch", err);
     }
     // samples of one pixel in flight per pass: 16 = one DPP row per pixel (ordered sums by row_newbcast), a 2x2 pixel footprint per
@@ -1980,7 +2004,8 @@ int launch_trace_rays(const DevScene& sc, const float* ox, const float* oy, cons
     if (lds > 160 * 1024) { err = "scene too deep for the LDS traversal stacks"; return MP_ERR_UNSUPPORTED; }
     const uint64_t chunks = (n + 63) / 64, want = (chunks + 3) / 4;
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(cu_count) * 8));
-    hipLaunchKernelGGL(trace_rays_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), P);
+    if (sc.inst_count != 0u) hipLaunchKernelGGL(trace_rays_kernel<true>, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), P);
+    else hipLaunchKernelGGL(trace_rays_kernel<false>, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), P);
     return check(hipGetLastError(), "trace_rays_kernel launch", err);
 }
 

@@ -73,6 +73,22 @@ int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err);
 // pkt_valid : real (unpadded) triangles of each packet (host staging for dlink; kept on the device for diagnostics).
 // shade     : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) material(u32 bits) pad.  48 B per triangle slot.
 // vidx/vtex : for the full HitRecord (texture_coords).
+// One member {object, translation} of a build-defined object group (mp_scene_group / mp_scene_instances): the member's own
+// traversal arrays (borrowed from its scene) and the translation that places it.  96 bytes.
+struct DevObject {
+    const float* shade;
+    const float* nodes_aos;
+    const float* tris_aos;
+    const uint32_t* vidx;
+    const float* vtex;
+    uint32_t root;
+    uint32_t has_pre;
+    float pre_min[3], pre_max[3];
+    float t[3];
+    uint32_t pad[3];
+};
+static_assert(sizeof(DevObject) == 96, "DevObject layout");
+
 struct DevScene {
     uint32_t kind = 0;               // 0 = TriangleBvh, 1 = Sphere (scene/primitives.rs:10-13)
     float sphere_center[3] = {0, 0, 0};
@@ -85,8 +101,8 @@ struct DevScene {
     const float* vtex = nullptr;     // nv*3
     const float* materials = nullptr;  // build-defined path extension: {albedo, emission} per material id (device)
     float sky = 1.0f;                  // ... and the sky radiance
-    uint32_t inst_count = 0;           // build-defined instanced Object: translations (device, xyz per instance); 0 = plain BVH
-    const float* inst_t = nullptr;
+    uint32_t inst_count = 0;           // build-defined object group: number of members; 0 = plain BVH
+    const struct DevObject* objects = nullptr;  // ... and their descriptors (device)
     uint32_t root = MP_LINK_NULL;    // dlink of the root
     uint32_t inner_count = 0;
     uint32_t packet_count = 0;

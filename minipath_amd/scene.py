@@ -199,6 +199,28 @@ class Instances(TriangleBvh):
         self.object = None
 
 
+class ObjectGroup(TriangleBvh):
+    """BUILD-DEFINED Object: a top-level list of members {object, translation} over any TriangleBvh scenes of one context
+    (mp_scene_group); hits carry the member index (`instance`) and the triangle index inside that member.  Shares the members'
+    device arrays: keeps references to them."""
+
+    def __init__(self, objects, translations):
+        objects = list(objects)
+        t = np.ascontiguousarray(translations, np.float32).reshape(-1, 3)
+        if len(objects) != t.shape[0] or not objects:
+            raise ValueError("one translation per member")
+        ctx = objects[0].ctx
+        arr = (C.c_void_p * len(objects))(*[o.handle for o in objects])
+        h = C.c_void_p()
+        _lib.check(_lib.lib().mp_scene_group(ctx.handle if ctx else None, arr, t.ctypes.data, len(objects), C.byref(h)))
+        super().__init__(h, ctx)
+        self.objects, self.translations = objects, t
+
+    def close(self):
+        super().close()  # before the members it borrows from
+        self.objects = []
+
+
 class Sphere(TriangleBvh):
     """scene/primitives.rs:10-56: analytic sphere as the scene's Object (same handle type, no BVH arrays)."""
 

@@ -547,6 +547,7 @@ struct mpo_bvh {
     float sky;
     /* build-defined Object: translated instances of this BVH (see scene_intersect); 0 = the plain TriangleBvh */
     uint32_t n_inst; float *inst_t;
+    const struct mpo_bvh **inst_obj; /* member objects of a group (NULL: every member is this BVH) */
 };
 
 typedef struct { float mn[3], mx[3]; } box3;
@@ -954,7 +955,7 @@ uint32_t mpo_bvh_material_count(const mpo_bvh *b) {
 
 void mpo_bvh_free(mpo_bvh *b) {
     if (!b) return;
-    free(b->inner); free(b->packets); free(b->shading); free(b->vnormal); free(b->vtex); free(b->material); free(b->mats); free(b->inst_t);
+    free(b->inner); free(b->packets); free(b->shading); free(b->vnormal); free(b->vtex); free(b->material); free(b->mats); free(b->inst_t); free(b->inst_obj);
     free(b);
 }
 
@@ -1225,9 +1226,11 @@ static void bvh_intersect_one(const mpo_bvh *b, const mpo_ray *ray, stack_cache 
 }
 
 /* BUILD-DEFINED Object (scene/mod.rs:7-10 `trait Object`; the reference has one object per Scene and no transforms): a list of
- * instances {this TriangleBvh, translation}.  intersect = for every instance in order: the object's own intersect with the ray
- * moved into the instance's frame (origin - translation; direction, hence t, unchanged), closest wins with a strict `<` (the
- * first instance keeps ties); HitRecord.point = point_at(t) of the WORLD ray; normal / tex / material are the object's. */
+ * members {TriangleBvh, translation} (mpo_bvh_set_group; mpo_bvh_set_instances = every member is this BVH).  intersect = for
+ * every member in order: the member's own intersect with the ray moved into the member's frame (origin - translation;
+ * direction, hence t, unchanged), closest wins with a strict `<` (the first member keeps ties); HitRecord.point = point_at(t)
+ * of the WORLD ray; normal / tex / material id are the member's, prim is the triangle index inside the member.  The material
+ * table and the sky radiance of the path extension are the container's (this BVH's). */
 static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache *st, mpo_hit *out, mpo_counters *cnt) {
     if (b->n_inst == 0) { bvh_intersect_one(b, ray, st, out, cnt); return; }
     mpo_hit best;
@@ -1238,8 +1241,8 @@ static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache
         mpo_ray r2 = *ray;
         for (int i = 0; i < 3; i++) r2.o[i] = ray->o[i] - b->inst_t[3 * k + i];
         mpo_hit h;
-        bvh_intersect_one(b, &r2, st, &h, cnt);
-        if (cnt) cnt->rays--; /* one Object::intersect call of the scene's object, however many instances it holds */
+        bvh_intersect_one(b->inst_obj ? b->inst_obj[k] : b, &r2, st, &h, cnt);
+        if (cnt) cnt->rays--; /* one Object::intersect call of the scene's object, however many members it holds */
         if (h.hit && h.t < best.t) { best = h; best.instance = k; }
     }
     if (cnt) cnt->rays++;
@@ -1247,10 +1250,24 @@ static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache
     *out = best;
 }
 
+int mpo_bvh_set_group(mpo_bvh *b, const mpo_bvh *const *objects, const float *translations, uint32_t n) {
+    if (n && objects)
+        for (uint32_t k = 0; k < n; k++)
+            if (!objects[k] || (objects[k] != b && objects[k]->n_inst)) return 0; /* members are plain BVHs (or the container) */
+    if (!mpo_bvh_set_instances(b, translations, n)) return 0;
+    if (n && objects) {
+        b->inst_obj = malloc((size_t)n * sizeof(*b->inst_obj));
+        memcpy(b->inst_obj, objects, (size_t)n * sizeof(*b->inst_obj));
+    }
+    return 1;
+}
+
 int mpo_bvh_set_instances(mpo_bvh *b, const float *translations, uint32_t n) {
     if (!b || (n && !translations)) return 0;
     free(b->inst_t);
+    free(b->inst_obj);
     b->inst_t = NULL;
+    b->inst_obj = NULL;
     b->n_inst = n;
     if (n) {
         b->inst_t = malloc((size_t)n * 3 * sizeof(float));

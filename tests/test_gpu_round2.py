@@ -337,6 +337,110 @@ def test_instanced_object(ctx, oracle, teapot_oracle_bvh):
     assert np.array_equal(bits(x), bits(y))
 
 
+def test_object_group_of_different_meshes(ctx, oracle):
+    """Multi-object scene ("a top-level list of {object, transform} behind the same Object entry points",
+    scene/mod.rs:7-15): members are DIFFERENT TriangleBvh scenes (teapot, a triangle soup with three material ids, a grid -- the
+    soup twice), each with its own tree depth, vertex arrays and material ids; one material table for the group.  Build-defined;
+    GPU == oracle bit for bit: full hit records with the member index and the member-local triangle index, frames at reference
+    semantics, the path extension with emissive / dark materials and a black sky, chunked sums over split passes."""
+    import ctypes as C
+
+    import torch
+
+    teapot = mp.TriangleBvh.with_obj(TEAPOT, ctx)
+    o_teapot = oracle.Bvh.from_obj(TEAPOT)
+    gpu, orc = [teapot], [o_teapot]
+    for name in ("soup_300", "grid_40"):
+        pos, nrm, tex, tri = meshes.make(name)
+        mat = (np.arange(tri.shape[0]) * 5 % 3).astype(np.uint32) if name == "soup_300" else None
+        gpu.append(mp.TriangleBvh.build(pos, nrm, tex, tri, ctx, tri_material=mat))
+        orc.append(oracle.Bvh.build(pos, nrm, tex, tri, tri_material=mat))
+    members = [0, 1, 2, 1]
+    tr = np.array([[0, 0, 0], [5.5, 1.5, -1.0], [-6.0, 2.0, -2.5], [0.5, 5.5, -3.0]], np.float32)
+    group = mp.ObjectGroup([gpu[k] for k in members], tr)
+    scene = mp.Scene(group)
+    table = [(0.8, 0.0), (0.2, 2.5), (0.6, 0.0)]
+    group.set_materials(table, 0.25)
+    box = oracle.Bvh.from_obj(TEAPOT)  # the container: its table and sky apply, its triangles are reached through member 0
+    box.set_group([box if k == 0 else orc[k] for k in members], tr)
+    box.set_materials(table, 0.25)
+    i = group.info()
+    assert i.triangle_count == sum(gpu[k].info().triangle_count for k in members) and i.material_count == 3
+    assert i.depth == max(g.info().depth for g in gpu) and i.stack_bound == max(g.info().stack_bound for g in gpu)
+    lo = np.min([np.array(list(gpu[k].info().bbox_min)) + tr[j] for j, k in enumerate(members)], axis=0)
+    hi = np.max([np.array(list(gpu[k].info().bbox_max)) + tr[j] for j, k in enumerate(members)], axis=0)
+    assert np.array_equal(np.array(list(i.bbox_min), np.float32), lo.astype(np.float32)) and np.array_equal(np.array(list(i.bbox_max), np.float32), hi.astype(np.float32))
+    # hits: every field of the HitRecord, which member, member-local triangle
+    o, d = meshes.random_rays(40000, 11, lo, hi)
+    got = group.intersect(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), full=True)
+    torch.cuda.synchronize()
+    t, prim, u, v, which = box.trace_inst(o, d)
+    assert np.array_equal(got["prim"].cpu().numpy().view(np.uint32), prim)
+    assert np.array_equal(got["instance"].cpu().numpy().view(np.uint32), which)
+    for k, e in (("t", t), ("u", u), ("v", v)):
+        assert np.array_equal(bits(got[k].cpu().numpy()), bits(e)), k
+    hit = prim != 0xFFFFFFFF
+    assert sorted(np.unique(which[hit]).tolist()) == [0, 1, 2, 3]
+    idx = np.flatnonzero(hit)
+    mats = set()
+    for j in idx[:: max(1, len(idx) // 400)]:
+        h = box.intersect(oracle.ray_new(o[j], d[j]))
+        assert np.array_equal(bits(got["point"].cpu().numpy()[j]), bits(np.array(list(h.point), np.float32)))
+        assert np.array_equal(bits(got["normal"].cpu().numpy()[j]), bits(np.array(list(h.normal), np.float32)))
+        assert np.array_equal(bits(got["tex"].cpu().numpy()[j]), bits(np.array(list(h.tex), np.float32)))
+        assert int(got["material"].cpu().numpy()[j]) == h.material
+        mats.add(h.material)
+    assert mats == {0, 1, 2}
+    # frames
+    eye, at = (1.0, 5.0, 19.0), (0.0, 2.5, -1.5)
+    oc = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(oc))
+    oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(*eye), oracle.vec3(*at), oracle.vec3(0, 1, 0))
+    cam = mp.Camera.default().look_at(eye, at, (0, 1, 0))
+    res = (176, 120)
+    osmp = oracle.build_sampler(oc, *res)
+    of, _, _, _, _ = box.render_image_mt(osmp, res[0], res[1], 6, 5, 32, 8)
+    for traversal in ("packets", "groups"):
+        a, seg = _render(scene, cam, mp.RenderSettings(32, 6, res, seed=5, traversal=traversal))
+        assert np.array_equal(bits(a), bits(of)), traversal
+        assert seg == res[0] * res[1] * 6
+    assert (of[..., 3] > 0).mean() > 0.1
+    for spp in (3, 8, 17):  # every samples-in-flight variant of the path kernel (1, 2, 4, 8)
+        pf, _, _, pseg = box.render_image_paths_mt(osmp, res[0], res[1], spp, 5, 6, 32, 8)
+        b, gseg = _render(scene, cam, mp.RenderSettings(32, spp, res, seed=5, max_depth=6))
+        assert np.array_equal(bits(b), bits(pf)) and gseg == pseg, spp
+    # chunked sums over split passes
+    st = mp.RenderSettings(32, 600, (64, 40), seed=5, max_depth=3, chunked_sum=True)
+    fr = mp.FrameRenderer(scene, mp.Camera.default().look_at(eye, at, (0, 1, 0)), st)
+    nxt = 0
+    for count in (100, 333, 0):
+        nxt = fr.render_pass(nxt, count)
+    img, _ = fr.untile()
+    torch.cuda.synchronize()
+    oc2 = oracle.build_sampler(oc, 64, 40)
+    oracle.lib().mpo_set_chunked_sum(1)
+    try:
+        cf, _, _, _ = box.render_image_paths_mt(oc2, 64, 40, 600, 5, 3, 32, 8)
+    finally:
+        oracle.lib().mpo_set_chunked_sum(0)
+    assert np.array_equal(bits(img.cpu().numpy()), bits(cf))
+    # what is not defined
+    with pytest.raises(mp.MinipathError):
+        mp.ObjectGroup([group, teapot], [[0, 0, 0], [1, 0, 0]])       # groups do not nest
+    with pytest.raises(mp.MinipathError):
+        mp.ObjectGroup([teapot, mp.Sphere((0, 0, 0), 1.0, ctx)], [[0, 0, 0], [1, 0, 0]])
+    with pytest.raises(mp.MinipathError):
+        group.export()                                                # a group has no arrays of its own
+    with pytest.raises(mp.MinipathError):
+        _render(scene, cam, mp.RenderSettings(32, 4, res, seed=3, max_depth=5, wavefront=True))
+    # a one-member group at the origin == the member itself
+    one = mp.Scene(mp.ObjectGroup([gpu[1]], [[0, 0, 0]]))
+    vcam = mp.Camera.default().look_at((0, 0, 9), (0, 0, 0), (0, 1, 0))
+    x, _ = _render(one, vcam, mp.RenderSettings(32, 6, (128, 96), seed=9, max_depth=4))
+    y, _ = _render(mp.Scene(gpu[1]), vcam, mp.RenderSettings(32, 6, (128, 96), seed=9, max_depth=4))
+    assert np.array_equal(bits(x), bits(y))
+
+
 def test_instances_keep_the_material_table_they_were_made_with(ctx, oracle):
     """Regression (found by tools/fuzz_gpu.py): an instanced scene shares its object's material table by reference; a later
     mp_scene_set_materials on the object gives the OBJECT a new table and must neither free the old one under the instanced scene

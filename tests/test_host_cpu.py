@@ -380,3 +380,65 @@ print("rc2", rc2)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "rc 7 " in r.stdout and "bad_alloc" in r.stdout, r.stdout  # MP_ERR_NOMEM
     assert "rc2 2" in r.stdout  # MP_ERR_IO
+
+
+def test_object_group_host_side():
+    """mp_scene_group without a GPU: counts are sums over the members, the box is the union of the translated boxes, the material
+    table covers the largest id any member uses; nesting, spheres and NULL members are refused; instances keep the object's counts."""
+    from tests import meshes
+
+    a = mp.TriangleBvh.with_obj(TEAPOT)
+    pos, nrm, tex, tri = meshes.make("soup_300")
+    b = mp.TriangleBvh.build(pos, nrm, tex, tri, tri_material=(np.arange(tri.shape[0]) % 4).astype(np.uint32))
+    tr = np.array([[0, 0, 0], [3, 1, 0], [-4, 0, 2]], np.float32)
+    g = mp.ObjectGroup([a, b, b], tr)
+    ia, ib, ig = a.info(), b.info(), g.info()
+    assert ig.triangle_count == ia.triangle_count + 2 * ib.triangle_count and ig.inner_count == ia.inner_count + 2 * ib.inner_count
+    assert ig.packet_count == ia.packet_count + 2 * ib.packet_count and ig.vertex_count == ia.vertex_count + 2 * ib.vertex_count
+    assert ig.material_count == 4 and ig.depth == max(ia.depth, ib.depth) and ig.stack_bound == 0
+    for k in range(3):
+        lo = min(ia.bbox_min[k] + tr[0, k], ib.bbox_min[k] + tr[1, k], ib.bbox_min[k] + tr[2, k])
+        hi = max(ia.bbox_max[k] + tr[0, k], ib.bbox_max[k] + tr[1, k], ib.bbox_max[k] + tr[2, k])
+        assert ig.bbox_min[k] == np.float32(lo) and ig.bbox_max[k] == np.float32(hi)
+    g.set_materials([(0.5, 0.0)] * 4, 1.0)
+    with pytest.raises(mp.MinipathError):
+        g.set_materials([(0.5, 0.0)] * 3, 1.0)  # shorter than the ids in use
+    with pytest.raises(mp.MinipathError):
+        g.export()
+    with pytest.raises(mp.MinipathError):
+        mp.ObjectGroup([g, a], [[0, 0, 0], [1, 0, 0]])
+    with pytest.raises(mp.MinipathError):
+        mp.ObjectGroup([a, mp.Sphere((0, 0, 0), 1.0)], [[0, 0, 0], [1, 0, 0]])
+    with pytest.raises(ValueError):
+        mp.ObjectGroup([a, b], [[0, 0, 0]])
+    inst = mp.Instances(b, tr)
+    ii = inst.info()
+    assert ii.triangle_count == ib.triangle_count and ii.inner_count == ib.inner_count and ii.material_count == 4
+    assert len(inst.export()) >= 5
+
+
+def test_oracle_group_is_the_members_traced_one_by_one():
+    """The oracle's object group (build-defined; parity unpinned: the reference has one object per Scene) equals its definition
+    spelled out with plain per-member traces: ray origin minus the member's translation, closest hit, first member keeps ties."""
+    from oracle import pyoracle as po
+    from tests import meshes
+
+    objs = [po.Bvh.from_obj(TEAPOT)] + [po.Bvh.build(*meshes.make(n)) for n in ("soup_300", "grid_40")]
+    members = [0, 1, 2, 1, 1]
+    tr = np.array([[0, 0, 0], [4, 1, 0], [-5, 2, -1], [4, 1, 0], [0, 6, 0]], np.float32)  # members 1 and 3 coincide: ties
+    box = po.Bvh.from_obj(TEAPOT)
+    box.set_group([box if k == 0 else objs[k] for k in members], tr)
+    o, d = meshes.random_rays(6000, 3, np.array([-8.0, -2, -4]), np.array([8.0, 9, 4]))
+    t, prim, u, v, which = box.trace_inst(o, d)
+    bt = np.full(len(o), np.finfo(np.float32).max, np.float32)
+    bp = np.full(len(o), 0xFFFFFFFF, np.uint32); bw = np.zeros(len(o), np.uint32)
+    bu = np.zeros(len(o), np.float32); bv = np.zeros(len(o), np.float32)
+    for j, k in enumerate(members):
+        tk, pk, uk, vk = objs[k].trace((o - tr[j]).astype(np.float32), d)
+        better = (pk != 0xFFFFFFFF) & (tk < bt)
+        bt[better], bp[better], bu[better], bv[better], bw[better] = tk[better], pk[better], uk[better], vk[better], j
+    hit = bp != 0xFFFFFFFF
+    assert hit.sum() > 500 and set(np.unique(bw[hit]).tolist()) >= {0, 1, 2, 4} and 3 not in set(bw[hit].tolist())
+    assert np.array_equal(prim, bp) and np.array_equal(which[hit], bw[hit])
+    for a, b in ((t, bt), (u, bu), (v, bv)):
+        assert np.array_equal(a[hit].view(np.uint32), b[hit].view(np.uint32))
