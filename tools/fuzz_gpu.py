@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the GPU render paths against the oracle: random small scenes, cameras (incl. axis-aligned views that
 produce zero direction components), resolutions, tile sizes, sample counts, kernels (packets / groups / fused paths / staged paths),
-work-unit sizes, progressive splits, material tables and sky radiance, instanced objects, the chunked accumulation rule.  Every
+work-unit sizes, progressive splits, material tables and sky radiance, instanced objects and object groups of different meshes, the
+chunked accumulation rule.  Every
 frame must match the oracle bit for bit.  usage: fuzz_gpu.py [cases] [seed]"""
 import ctypes as C, os, sys
 import numpy as np
@@ -53,9 +54,18 @@ def run(cases, seed, ctx=None):
         sky = float(rng.choice([1.0, 0.0, 0.4]))
         scene.object.set_materials(table, sky); ob.set_materials(table, sky)
         use = scene
-        if mode != "staged" and rng.random() < 0.2:   # instanced object: 2-4 translated copies
+        pick = rng.random()
+        if mode != "staged" and pick < 0.15:   # instanced object: 2-4 translated copies
             tr = (rng.normal(size=(int(rng.integers(2, 5)), 3)) * 3.0).astype(np.float32)
             use = mp.Scene(mp.Instances(scene.object, tr)); ob.set_instances(tr)
+        elif mode != "staged" and pick < 0.3:   # object group: 2-4 members drawn from all the scenes (this one is the container)
+            names = [name] + [list(scenes)[int(rng.integers(len(scenes)))] for _ in range(int(rng.integers(1, 4)))]
+            order = rng.permutation(len(names))
+            names = [names[i] for i in order]
+            tr = (rng.normal(size=(len(names), 3)) * 3.0).astype(np.float32)
+            grp = mp.ObjectGroup([scenes[m][0].object for m in names], tr)
+            grp.set_materials(table, sky)
+            use = mp.Scene(grp); ob.set_group([scenes[m][1] for m in names], tr)
         else:
             ob.set_instances(np.zeros((0, 3), np.float32))
         po.lib().mpo_set_chunked_sum(1 if chunked else 0)
