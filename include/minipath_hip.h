@@ -226,11 +226,12 @@ const char *mp_scene_material_name(const mp_scene *scene, uint32_t id);
 /* scene/primitives.rs:10-56 Sphere as the scene's Object (analytic intersection, no BVH).  ctx may be NULL (host-only). */
 int mp_scene_sphere(mp_ctx *ctx, const float center[3], float radius, mp_scene **out);
 /* BUILD-DEFINED Object (scene/mod.rs:7-10 `trait Object`; the reference's Scene holds ONE object and has no transforms): a
- * top-level list of n members {object, translation} (objects: n TriangleBvh scenes of this context, repeats allowed;
- * translations: n*3 floats, copied).  intersect = for every member in order the member's own intersect with the ray moved into
+ * top-level list of n members {object, translation} (objects: n TriangleBvh or Sphere scenes of this context -- the reference's
+ * two Object implementations -- repeats allowed, groups do not nest; translations: n*3 floats, copied).  intersect = for every member in order the member's own intersect with the ray moved into
  * the member's frame (origin - translation; direction and t unchanged), closest wins with a strict `<` (the first member keeps
  * ties); HitRecord.point = point_at(t) of the world ray, normal / tex / material id are the member's; mp_hits_soa.d_instance =
- * index of the member that was hit, prim = triangle index inside that member.  The group has ONE material table indexed by the
+ * index of the member that was hit, prim = triangle index inside that member (0, material 0 and texture_coords 0 for a Sphere
+ * member, primitives.rs:40-46).  The group has ONE material table indexed by the
  * members' material ids (initially the first member's, padded with the default material; mp_scene_set_materials replaces it)
  * and the first member's sky radiance.  get_bounding_box = union of the translated boxes; mp_scene_info counts are sums over the
  * members.  The group SHARES its members' device arrays: they must outlive it.  Rendered by the 8-lane-group traversal (every

@@ -736,7 +736,8 @@ int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* transla
     for (uint32_t i = 0; i < n; i++) {
         const mp_scene* o = objects[i];
         if (!o) return fail(MP_ERR_INVALID, "NULL member");
-        if (o->dev.kind != 0u || o->inst_of) return fail(MP_ERR_UNSUPPORTED, "the members of an object group are TriangleBvh scenes");
+        if (o->inst_of) return fail(MP_ERR_UNSUPPORTED, "the members of an object group are TriangleBvh or Sphere scenes, not groups");
+        if (one_object && o->dev.kind != 0u) return fail(MP_ERR_UNSUPPORTED, "instances are made of a TriangleBvh scene");
         if (o->ctx != ctx) return fail(MP_ERR_INVALID, "member belongs to another context");
     }
     auto s = std::make_unique<mp_scene>();
@@ -748,7 +749,10 @@ int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* transla
     s->host.root = objects[0]->host.root;
     s->host.material_names = objects[0]->host.material_names;
     s->material_count = 1;
-    s->dev = objects[0]->dev;
+    s->dev = DevScene{};  // kind 0; every geometry field comes from the member descriptors
+    s->dev.packet_stack_regs = objects[0]->dev.packet_stack_regs;
+    s->dev.materials = objects[0]->dev.materials;
+    s->dev.sky = objects[0]->sky;
     for (uint32_t i = 0; i < n; i++) {
         const mp_scene* o = objects[i];
         s->host.depth = std::max(s->host.depth, o->host.depth);
@@ -773,7 +777,6 @@ int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* transla
     s->materials = objects[0]->materials;
     if (s->materials.size() < s->material_count) s->materials.resize(s->material_count, mp_material{0.75f, 0.0f});
     s->sky = objects[0]->sky;
-    s->mat_table = objects[0]->mat_table;  // a snapshot: a later mp_scene_set_materials on the member does not reach the group
     s->dev.inst_count = n;
     s->dev.has_pre = 0;
     if (ctx) {
@@ -785,14 +788,18 @@ int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* transla
             std::memset(&o, 0, sizeof(o));
             o.shade = d.shade; o.nodes_aos = d.nodes_aos; o.tris_aos = d.tris_aos; o.vidx = d.vidx; o.vtex = d.vtex;
             o.root = d.root; o.has_pre = d.has_pre;
-            for (int k = 0; k < 3; k++) { o.pre_min[k] = d.pre_min[k]; o.pre_max[k] = d.pre_max[k]; o.t[k] = translations[3 * i + k]; }
+            o.kind = d.kind; o.sphere_radius = d.sphere_radius;
+            for (int k = 0; k < 3; k++) {
+                o.pre_min[k] = d.pre_min[k]; o.pre_max[k] = d.pre_max[k]; o.t[k] = translations[3 * i + k];
+                o.sphere_center[k] = d.sphere_center[k];
+            }
         }
         MP_HIP(hipMalloc(&s->d_inst, desc.size() * sizeof(DevObject)));
         hipError_t e = hipMemcpy(s->d_inst, desc.data(), desc.size() * sizeof(DevObject), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(s->d_inst); return hip_fail(e, "hipMemcpy(object group)"); }
         s->dev.objects = static_cast<const DevObject*>(s->d_inst);
         s->device_bytes = desc.size() * sizeof(DevObject);
-        if (s->materials.size() != objects[0]->materials.size()) {  // padded table: the group needs its own device copy
+        {  // the group's own copy of the table: a later mp_scene_set_materials on a member does not reach the group
             auto tb = std::make_shared<mp_scene::DevTable>();
             tb->device = ctx->device;
             MP_HIP(hipMalloc(&tb->d, std::max<size_t>(16, s->materials.size() * sizeof(mp_material))));

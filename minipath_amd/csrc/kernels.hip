@@ -334,65 +334,6 @@ __device__ __forceinline__ bool may_hit_scene(const DevScene& sc, const Ray& r) 
     return t1 <= t2;
 }
 
-// Build-defined object group (mp_scene_group / mp_scene_instances): the scene seen as member k -- the member's own traversal
-// arrays under the group's material table and stack bound.  k is wave-uniform in the pass over member k (scalar loads) and per
-// lane when a lane shades the member its ray hit.
-__device__ __forceinline__ void object_scene(const DevScene& sc, uint32_t k, DevScene& sk) {
-    sk = sc;
-    const DevObject& o = sc.objects[k];
-    sk.shade = o.shade; sk.nodes_aos = o.nodes_aos; sk.tris_aos = o.tris_aos; sk.vidx = o.vidx; sk.vtex = o.vtex;
-    sk.root = o.root; sk.has_pre = o.has_pre;
-    for (int i = 0; i < 3; i++) { sk.pre_min[i] = o.pre_min[i]; sk.pre_max[i] = o.pre_max[i]; }
-}
-// ... and the ray in member k's frame (origin - translation; direction, hence t, unchanged)
-__device__ __forceinline__ void object_ray(const DevScene& sc, uint32_t k, const Ray& r, Ray& rk) {
-    const float* t = sc.objects[k].t;
-    rk = r;
-    rk.ox = r.ox - t[0]; rk.oy = r.oy - t[1]; rk.oz = r.oz - t[2];
-}
-
-struct GroupHit {
-    float t, u, v;
-    uint32_t prim, inst;
-};
-
-// Closest hit of the wave's rays (one per lane, `act` = lane holds a ray) with the group walk: compaction of the lanes whose ray
-// can reach the object into the wave's ray queue, trace_wave, results back to the lanes.  OBJ: once per member of the object
-// group, in order, closest wins with a strict `<` (the first member keeps ties).
-template <bool OBJ, bool BFE = false>
-__device__ __forceinline__ void trace_objects(const DevScene& sc, const Ray& r, bool act, float* __restrict__ q,
-                                              uint2* __restrict__ stack, uint64_t lanes_lt, GroupHit& h) {
-    h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim; h.inst = 0u;
-    auto pass = [&](const DevScene& sk, const Ray& rk, uint32_t k) {
-        const bool queued = act && may_hit_scene(sk, rk);
-        const uint64_t am = __ballot(queued);
-        const int n = __popcll(am), rank = __popcll(am & lanes_lt);
-        if (queued) {
-            q[0 * 64 + rank] = rk.ox; q[1 * 64 + rank] = rk.oy; q[2 * 64 + rank] = rk.oz;
-            q[3 * 64 + rank] = rk.dx; q[4 * 64 + rank] = rk.dy; q[5 * 64 + rank] = rk.dz;
-        }
-        wave_lds_sync();
-        trace_wave<BFE>(sk, q, stack, n);
-        if (queued) {
-            const uint32_t prim = as_u(q[1 * 64 + rank]);
-            const float t = q[0 * 64 + rank];
-            if (prim != kNoPrim && t < h.t) { h.t = t; h.prim = prim; h.u = q[2 * 64 + rank]; h.v = q[3 * 64 + rank]; h.inst = k; }
-        }
-        wave_lds_sync();
-    };
-    if (!OBJ) {
-        pass(sc, r, 0u);
-        return;
-    }
-    for (uint32_t k = 0; k < sc.inst_count; k++) {
-        DevScene sk;
-        Ray rk;
-        object_scene(sc, k, sk);
-        object_ray(sc, k, r, rk);
-        pass(sk, rk, k);
-    }
-}
-
 // Hit resolve + shade: tail of intersect (ray_bvh_intersection.rs:66-95) and render_sample (worker.rs:59-65).
 // Returns |dot(ray.direction, normal)|.
 // Returns TriangleShadingData.material of the triangle (mod.rs:44; 0 for everything the reference builds).
@@ -435,6 +376,87 @@ __device__ __forceinline__ bool sphere_intersect(const DevScene& sc, const Ray& 
     const float len = sqrtf(nx * nx + ny * ny + nz * nz);
     n[0] = nx / len; n[1] = ny / len; n[2] = nz / len;
     return true;
+}
+
+// Build-defined object group (mp_scene_group / mp_scene_instances): the scene seen as member k -- the member's own traversal
+// arrays under the group's material table and stack bound.  k is wave-uniform in the pass over member k (scalar loads) and per
+// lane when a lane shades the member its ray hit.
+__device__ __forceinline__ void object_scene(const DevScene& sc, uint32_t k, DevScene& sk) {
+    sk = sc;
+    const DevObject& o = sc.objects[k];
+    sk.shade = o.shade; sk.nodes_aos = o.nodes_aos; sk.tris_aos = o.tris_aos; sk.vidx = o.vidx; sk.vtex = o.vtex;
+    sk.root = o.root; sk.has_pre = o.has_pre;
+    sk.kind = o.kind; sk.sphere_radius = o.sphere_radius;
+    for (int i = 0; i < 3; i++) { sk.pre_min[i] = o.pre_min[i]; sk.pre_max[i] = o.pre_max[i]; sk.sphere_center[i] = o.sphere_center[i]; }
+}
+// ... and the ray in member k's frame (origin - translation; direction, hence t, unchanged)
+__device__ __forceinline__ void object_ray(const DevScene& sc, uint32_t k, const Ray& r, Ray& rk) {
+    const float* t = sc.objects[k].t;
+    rk = r;
+    rk.ox = r.ox - t[0]; rk.oy = r.oy - t[1]; rk.oz = r.oz - t[2];
+}
+
+struct GroupHit {
+    float t, u, v;
+    uint32_t prim, inst;
+};
+
+// Closest hit of the wave's rays (one per lane, `act` = lane holds a ray) with the group walk: compaction of the lanes whose ray
+// can reach the object into the wave's ray queue, trace_wave, results back to the lanes.  OBJ: once per member of the object
+// group, in order, closest wins with a strict `<` (the first member keeps ties).
+template <bool OBJ, bool BFE = false>
+__device__ __forceinline__ void trace_objects(const DevScene& sc, const Ray& r, bool act, float* __restrict__ q,
+                                              uint2* __restrict__ stack, uint64_t lanes_lt, GroupHit& h) {
+    h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim; h.inst = 0u;
+    auto pass = [&](const DevScene& sk, const Ray& rk, uint32_t k) {
+        if (OBJ && sk.kind == 1u) {  // a Sphere member (scene/primitives.rs:16-48): lane-parallel, no walk; prim 0
+            float ts, nn[3];
+            if (act && sphere_intersect(sk, rk, ts, nn) && ts < h.t) { h.t = ts; h.prim = 0u; h.u = h.v = 0.0f; h.inst = k; }
+            return;
+        }
+        const bool queued = act && may_hit_scene(sk, rk);
+        const uint64_t am = __ballot(queued);
+        const int n = __popcll(am), rank = __popcll(am & lanes_lt);
+        if (queued) {
+            q[0 * 64 + rank] = rk.ox; q[1 * 64 + rank] = rk.oy; q[2 * 64 + rank] = rk.oz;
+            q[3 * 64 + rank] = rk.dx; q[4 * 64 + rank] = rk.dy; q[5 * 64 + rank] = rk.dz;
+        }
+        wave_lds_sync();
+        trace_wave<BFE>(sk, q, stack, n);
+        if (queued) {
+            const uint32_t prim = as_u(q[1 * 64 + rank]);
+            const float t = q[0 * 64 + rank];
+            if (prim != kNoPrim && t < h.t) { h.t = t; h.prim = prim; h.u = q[2 * 64 + rank]; h.v = q[3 * 64 + rank]; h.inst = k; }
+        }
+        wave_lds_sync();
+    };
+    if (!OBJ) {
+        pass(sc, r, 0u);
+        return;
+    }
+    for (uint32_t k = 0; k < sc.inst_count; k++) {
+        DevScene sk;
+        Ray rk;
+        object_scene(sc, k, sk);
+        object_ray(sc, k, r, rk);
+        pass(sk, rk, k);
+    }
+}
+
+// Normal and material id of a hit on member `inst` of an object group (r = the world ray).  A Sphere member's normal is that of
+// its intersect, evaluated again on the ray in the member's frame (same operations, same bits); material 0 (primitives.rs:40-46).
+__device__ __forceinline__ uint32_t object_normal(const DevScene& sc, uint32_t inst, const Ray& r, uint32_t prim, float u, float v,
+                                                  float n[3]) {
+    DevScene so;
+    object_scene(sc, inst, so);
+    if (so.kind == 1u) {
+        Ray rk;
+        object_ray(sc, inst, r, rk);
+        float t;
+        sphere_intersect(so, rk, t, n);
+        return 0u;
+    }
+    return resolve_normal(so, prim, u, v, n);
 }
 
 // ---- fused tile render: Worker::render_tile (worker.rs:32-49) for a list of tiles -----------------------------
@@ -575,13 +597,8 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
             float c = 0.0f, h = 0.0f;
             if (gh.prim != kNoPrim) {
                 float nn[3];
-                if (OBJ) {
-                    DevScene so;
-                    object_scene(P.scene, gh.inst, so);
-                    resolve_normal(so, gh.prim, gh.u, gh.v, nn);
-                } else {
-                    resolve_normal(P.scene, gh.prim, gh.u, gh.v, nn);
-                }
+                if (OBJ) object_normal(P.scene, gh.inst, r, gh.prim, gh.u, gh.v, nn);
+                else resolve_normal(P.scene, gh.prim, gh.u, gh.v, nn);
                 c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60
                 h = 1.0f;
             }
@@ -1237,15 +1254,16 @@ constexpr float kPathEps = 1e-4f;
 // One path vertex of the build-defined extension (oracle: render_sample_paths_impl), shared by the fused and the staged kernels so
 // that both evaluate the very same operations: `h` is the closest hit of segment `depth` along `r`.  Updates L / thr, and either
 // ends the path (returns false) or replaces `r` by the bounce ray drawn from `rng` (returns true).
+template <bool OBJ = false>
 __device__ __forceinline__ bool path_vertex(const DevScene& sc, const PacketHit& h, uint32_t depth, uint32_t max_depth, Rng& rng,
-                                            Ray& r, float& L, float& thr, bool& primary_hit) {
+                                            Ray& r, float& L, float& thr, bool& primary_hit, uint32_t inst = 0u) {
     if (h.prim == kNoPrim) {
         L = L + thr * sc.sky;
         return false;
     }
     if (depth == 1) primary_hit = true;
     float n[3];
-    const uint32_t mat = resolve_normal(sc, h.prim, h.u, h.v, n);
+    const uint32_t mat = OBJ ? object_normal(sc, inst, r, h.prim, h.u, h.v, n) : resolve_normal(sc, h.prim, h.u, h.v, n);
     const float2 m = reinterpret_cast<const float2*>(sc.materials)[mat];  // {albedo, emission}
     L = L + thr * m.y;
     const float dn = r.dx * n[0] + r.dy * n[1] + r.dz * n[2];
@@ -1331,15 +1349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                     h.t = gh.t; h.u = gh.u; h.v = gh.v; h.prim = gh.prim;
                     hinst = gh.inst;
                 }
-                if (alive) {
-                    if (OBJ) {
-                        DevScene so = P.scene;
-                        if (h.prim != kNoPrim) object_scene(P.scene, hinst, so);
-                        alive = path_vertex(so, h, depth, P.max_depth, rng, r, L, thr, primary_hit);
-                    } else {
-                        alive = path_vertex(P.scene, h, depth, P.max_depth, rng, r, L, thr, primary_hit);
-                    }
-                }
+                if (alive) alive = path_vertex<OBJ>(P.scene, h, depth, P.max_depth, rng, r, L, thr, primary_hit, hinst);
             }
             cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
             add_samples_in_order<S>(acc, L, lane);
@@ -1684,17 +1694,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 float pt[3] = {0, 0, 0}, nn[3] = {0, 0, 0}, tx[3] = {0, 0, 0};
                 uint32_t mat = 0;  // HitRecord.material (geometry/mod.rs:78)
                 if (prim != kNoPrim) {
-                    DevScene so = P.scene;  // the member the ray hit (its normals, texture coordinates, material ids)
-                    if (OBJ) object_scene(P.scene, inst, so);
-                    mat = resolve_normal(so, prim, u, v, nn);
                     Ray r;  // rebuilt here so that no ray registers stay live across the walk
                     ray_new(P.ox[i], P.oy[i], P.oz[i], P.dx[i], P.dy[i], P.dz[i], r);
+                    DevScene so = P.scene;  // the member the ray hit (its normals, texture coordinates, material ids)
+                    if (OBJ) object_scene(P.scene, inst, so);
+                    mat = OBJ ? object_normal(P.scene, inst, r, prim, u, v, nn) : resolve_normal(so, prim, u, v, nn);
                     pt[0] = r.ox + r.dx * t; pt[1] = r.oy + r.dy * t; pt[2] = r.oz + r.dz * t;  // geometry/mod.rs:56-58
-                    const uint32_t* vi = so.vidx + static_cast<size_t>(prim) * 3;
-                    const float *t0 = so.vtex + 3 * static_cast<size_t>(vi[0]), *t1 = so.vtex + 3 * static_cast<size_t>(vi[1]),
-                                *t2 = so.vtex + 3 * static_cast<size_t>(vi[2]);
-                    float w = 1.0f - u - v;
-                    for (int k = 0; k < 3; k++) tx[k] = t0[k] * w + t1[k] * u + t2[k] * v;
+                    if (!OBJ || so.kind == 0u) {  // a Sphere member's texture_coords are the origin (primitives.rs:45)
+                        const uint32_t* vi = so.vidx + static_cast<size_t>(prim) * 3;
+                        const float *t0 = so.vtex + 3 * static_cast<size_t>(vi[0]), *t1 = so.vtex + 3 * static_cast<size_t>(vi[1]),
+                                    *t2 = so.vtex + 3 * static_cast<size_t>(vi[2]);
+                        float w = 1.0f - u - v;
+                        for (int k = 0; k < 3; k++) tx[k] = t0[k] * w + t1[k] * u + t2[k] * v;
+                    }
                 }
                 for (int k = 0; k < 3; k++) {
                     if (P.hits.d_point) P.hits.d_point[i * 3 + k] = pt[k];

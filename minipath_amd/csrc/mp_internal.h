@@ -74,7 +74,7 @@ int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err);
 // shade     : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) material(u32 bits) pad.  48 B per triangle slot.
 // vidx/vtex : for the full HitRecord (texture_coords).
 // One member {object, translation} of a build-defined object group (mp_scene_group / mp_scene_instances): the member's own
-// traversal arrays (borrowed from its scene) and the translation that places it.  96 bytes.
+// traversal arrays (borrowed from its scene) or its sphere, and the translation that places it.  112 bytes.
 struct DevObject {
     const float* shade;
     const float* nodes_aos;
@@ -85,9 +85,12 @@ struct DevObject {
     uint32_t has_pre;
     float pre_min[3], pre_max[3];
     float t[3];
-    uint32_t pad[3];
+    uint32_t kind;              // 0 = TriangleBvh, 1 = Sphere (scene/primitives.rs:10-13)
+    float sphere_center[3];
+    float sphere_radius;
+    uint32_t pad[2];
 };
-static_assert(sizeof(DevObject) == 96, "DevObject layout");
+static_assert(sizeof(DevObject) == 112, "DevObject layout");
 
 struct DevScene {
     uint32_t kind = 0;               // 0 = TriangleBvh, 1 = Sphere (scene/primitives.rs:10-13)

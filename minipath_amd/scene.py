@@ -200,8 +200,8 @@ class Instances(TriangleBvh):
 
 
 class ObjectGroup(TriangleBvh):
-    """BUILD-DEFINED Object: a top-level list of members {object, translation} over any TriangleBvh scenes of one context
-    (mp_scene_group); hits carry the member index (`instance`) and the triangle index inside that member.  Shares the members'
+    """BUILD-DEFINED Object: a top-level list of members {object, translation} over any TriangleBvh or Sphere scenes of one
+    context (mp_scene_group); hits carry the member index (`instance`) and the triangle index inside that member.  Shares the members'
     device arrays: keeps references to them."""
 
     def __init__(self, objects, translations):

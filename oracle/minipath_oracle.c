@@ -548,6 +548,7 @@ struct mpo_bvh {
     /* build-defined Object: translated instances of this BVH (see scene_intersect); 0 = the plain TriangleBvh */
     uint32_t n_inst; float *inst_t;
     const struct mpo_bvh **inst_obj; /* member objects of a group (NULL: every member is this BVH) */
+    float *inst_sph;                  /* group: 4 floats per member {center, radius}; radius < 0 = the member is a BVH */
 };
 
 typedef struct { float mn[3], mx[3]; } box3;
@@ -955,7 +956,7 @@ uint32_t mpo_bvh_material_count(const mpo_bvh *b) {
 
 void mpo_bvh_free(mpo_bvh *b) {
     if (!b) return;
-    free(b->inner); free(b->packets); free(b->shading); free(b->vnormal); free(b->vtex); free(b->material); free(b->mats); free(b->inst_t); free(b->inst_obj);
+    free(b->inner); free(b->packets); free(b->shading); free(b->vnormal); free(b->vtex); free(b->material); free(b->mats); free(b->inst_t); free(b->inst_obj); free(b->inst_sph);
     free(b);
 }
 
@@ -1241,7 +1242,11 @@ static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache
         mpo_ray r2 = *ray;
         for (int i = 0; i < 3; i++) r2.o[i] = ray->o[i] - b->inst_t[3 * k + i];
         mpo_hit h;
-        bvh_intersect_one(b->inst_obj ? b->inst_obj[k] : b, &r2, st, &h, cnt);
+        if (b->inst_sph && b->inst_sph[4 * k + 3] >= 0.0f) { /* a Sphere member (primitives.rs:16-48): material 0, tex = origin */
+            mpo_sphere_intersect(&b->inst_sph[4 * k], b->inst_sph[4 * k + 3], &r2, &h);
+            if (cnt) cnt->rays++;
+        } else
+            bvh_intersect_one(b->inst_obj ? b->inst_obj[k] : b, &r2, st, &h, cnt);
         if (cnt) cnt->rays--; /* one Object::intersect call of the scene's object, however many members it holds */
         if (h.hit && h.t < best.t) { best = h; best.instance = k; }
     }
@@ -1250,14 +1255,21 @@ static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache
     *out = best;
 }
 
-int mpo_bvh_set_group(mpo_bvh *b, const mpo_bvh *const *objects, const float *translations, uint32_t n) {
+int mpo_bvh_set_group(mpo_bvh *b, const mpo_bvh *const *objects, const float *spheres, const float *translations, uint32_t n) {
     if (n && objects)
-        for (uint32_t k = 0; k < n; k++)
+        for (uint32_t k = 0; k < n; k++) {
+            const int sphere = spheres && spheres[4 * k + 3] >= 0.0f;
+            if (sphere) continue;
             if (!objects[k] || (objects[k] != b && objects[k]->n_inst)) return 0; /* members are plain BVHs (or the container) */
+        }
     if (!mpo_bvh_set_instances(b, translations, n)) return 0;
     if (n && objects) {
         b->inst_obj = malloc((size_t)n * sizeof(*b->inst_obj));
         memcpy(b->inst_obj, objects, (size_t)n * sizeof(*b->inst_obj));
+    }
+    if (n && spheres) {
+        b->inst_sph = malloc((size_t)n * 4 * sizeof(float));
+        memcpy(b->inst_sph, spheres, (size_t)n * 4 * sizeof(float));
     }
     return 1;
 }
@@ -1266,8 +1278,10 @@ int mpo_bvh_set_instances(mpo_bvh *b, const float *translations, uint32_t n) {
     if (!b || (n && !translations)) return 0;
     free(b->inst_t);
     free(b->inst_obj);
+    free(b->inst_sph);
     b->inst_t = NULL;
     b->inst_obj = NULL;
+    b->inst_sph = NULL;
     b->n_inst = n;
     if (n) {
         b->inst_t = malloc((size_t)n * 3 * sizeof(float));

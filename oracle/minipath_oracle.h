@@ -174,9 +174,11 @@ uint32_t mpo_bvh_material_count(const mpo_bvh *b);            /* max id + 1 */
 /* BUILD-DEFINED Object: n translated instances of this BVH (n*3 floats; n = 0 restores the plain TriangleBvh).  Every
  * intersect / render entry point then treats the list as the scene's object (see scene semantics in the .c file). */
 int mpo_bvh_set_instances(mpo_bvh *b, const float *translations, uint32_t n);
-/* ... n members {objects[k], translation k} (plain BVHs; objects[k] may be b itself); b is the container: its material table
- * and sky apply, its own triangles are only reachable through members that name it.  The members must outlive b's use. */
-int mpo_bvh_set_group(mpo_bvh *b, const mpo_bvh *const *objects, const float *translations, uint32_t n);
+/* ... n members {object k, translation k}: objects[k] = a plain BVH (may be b itself), or -- where spheres (4 floats per member:
+ * center, radius; NULL = no sphere members) has radius >= 0 -- a Sphere (scene/primitives.rs:10-56; objects[k] is then ignored).
+ * b is the container: its material table and sky apply, its own triangles are only reachable through members that name it.  The
+ * members must outlive b's use. */
+int mpo_bvh_set_group(mpo_bvh *b, const mpo_bvh *const *objects, const float *spheres, const float *translations, uint32_t n);
 void mpo_bvh_free(mpo_bvh *b);
 uint32_t mpo_bvh_root(const mpo_bvh *b);
 void mpo_bvh_bbox(const mpo_bvh *b, float bmin[3], float bmax[3]);

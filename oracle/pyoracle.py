@@ -159,7 +159,7 @@ def lib() -> C.CDLL:
     L.mpo_set_chunked_sum.argtypes = [C.c_int]
     L.mpo_bvh_set_instances.argtypes = [C.c_void_p, f32p, C.c_uint32]
     L.mpo_bvh_set_instances.restype = C.c_int
-    L.mpo_bvh_set_group.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), f32p, C.c_uint32]
+    L.mpo_bvh_set_group.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), f32p, f32p, C.c_uint32]
     L.mpo_bvh_set_group.restype = C.c_int
     L.mpo_trace_rays_inst.argtypes = [C.c_void_p] + [f32p] * 6 + [C.c_uint64, f32p, u32p, f32p, f32p, u32p]
     L.mpo_seed_mix.argtypes = [C.c_uint64]
@@ -343,12 +343,17 @@ class Bvh:
             raise RuntimeError("set_instances failed")
 
     def set_group(self, objects, translations) -> None:
-        """BUILD-DEFINED Object: members {objects[k], translation k}; this BVH is the container (its materials and sky apply).
-        Keeps references to the members."""
+        """BUILD-DEFINED Object: members {objects[k], translation k}; a member is a Bvh or a sphere given as (center, radius).
+        This BVH is the container (its materials and sky apply).  Keeps references to the members."""
         t = np.ascontiguousarray(translations, np.float32).reshape(-1, 3)
         objects = list(objects)
-        arr = (C.c_void_p * len(objects))(*[o.h for o in objects])
-        if len(objects) != t.shape[0] or not lib().mpo_bvh_set_group(self.h, arr, _f32p(t), t.shape[0]):
+        sph = np.full((len(objects), 4), -1.0, np.float32)
+        for k, o in enumerate(objects):
+            if not isinstance(o, Bvh):
+                sph[k, :3], sph[k, 3] = o[0], o[1]
+        arr = (C.c_void_p * len(objects))(*[o.h if isinstance(o, Bvh) else None for o in objects])
+        has_sphere = bool((sph[:, 3] >= 0).any())
+        if len(objects) != t.shape[0] or not lib().mpo_bvh_set_group(self.h, arr, _f32p(sph) if has_sphere else None, _f32p(t), t.shape[0]):
             raise RuntimeError("set_group failed")
         self._members = objects
 

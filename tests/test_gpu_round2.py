@@ -339,8 +339,9 @@ def test_instanced_object(ctx, oracle, teapot_oracle_bvh):
 
 def test_object_group_of_different_meshes(ctx, oracle):
     """Multi-object scene ("a top-level list of {object, transform} behind the same Object entry points",
-    scene/mod.rs:7-15): members are DIFFERENT TriangleBvh scenes (teapot, a triangle soup with three material ids, a grid -- the
-    soup twice), each with its own tree depth, vertex arrays and material ids; one material table for the group.  Build-defined;
+    scene/mod.rs:7-15): members are DIFFERENT objects (teapot, a triangle soup with three material ids -- twice --, a grid, and a
+    Sphere, the reference's other Object), each with its own tree depth, vertex arrays and material ids; one material table for
+    the group.  Build-defined;
     GPU == oracle bit for bit: full hit records with the member index and the member-local triangle index, frames at reference
     semantics, the path extension with emissive / dark materials and a black sky, chunked sums over split passes."""
     import ctypes as C
@@ -355,8 +356,11 @@ def test_object_group_of_different_meshes(ctx, oracle):
         mat = (np.arange(tri.shape[0]) * 5 % 3).astype(np.uint32) if name == "soup_300" else None
         gpu.append(mp.TriangleBvh.build(pos, nrm, tex, tri, ctx, tri_material=mat))
         orc.append(oracle.Bvh.build(pos, nrm, tex, tri, tri_material=mat))
-    members = [0, 1, 2, 1]
-    tr = np.array([[0, 0, 0], [5.5, 1.5, -1.0], [-6.0, 2.0, -2.5], [0.5, 5.5, -3.0]], np.float32)
+    ball = mp.Sphere((0.0, 0.5, 0.0), 1.25, ctx)  # the reference's other Object (scene/primitives.rs:10-56) as a member
+    gpu.append(ball)
+    orc.append(((0.0, 0.5, 0.0), 1.25))
+    members = [0, 1, 3, 2, 1]
+    tr = np.array([[0, 0, 0], [5.5, 1.5, -1.0], [-2.5, 4.5, 2.0], [-6.0, 2.0, -2.5], [0.5, 5.5, -3.0]], np.float32)
     group = mp.ObjectGroup([gpu[k] for k in members], tr)
     scene = mp.Scene(group)
     table = [(0.8, 0.0), (0.2, 2.5), (0.6, 0.0)]
@@ -380,10 +384,13 @@ def test_object_group_of_different_meshes(ctx, oracle):
     for k, e in (("t", t), ("u", u), ("v", v)):
         assert np.array_equal(bits(got[k].cpu().numpy()), bits(e)), k
     hit = prim != 0xFFFFFFFF
-    assert sorted(np.unique(which[hit]).tolist()) == [0, 1, 2, 3]
-    idx = np.flatnonzero(hit)
+    assert sorted(np.unique(which[hit]).tolist()) == [0, 1, 2, 3, 4]
+    on_ball = hit & (which == 2)
+    assert on_ball.sum() > 300 and np.all(prim[on_ball] == 0) and np.all(got["material"].cpu().numpy()[on_ball] == 0)
+    assert not got["tex"].cpu().numpy()[on_ball].any()
+    idx = np.concatenate([np.flatnonzero(hit)[:: max(1, int(hit.sum()) // 400)], np.flatnonzero(on_ball)[:60]])
     mats = set()
-    for j in idx[:: max(1, len(idx) // 400)]:
+    for j in idx:
         h = box.intersect(oracle.ray_new(o[j], d[j]))
         assert np.array_equal(bits(got["point"].cpu().numpy()[j]), bits(np.array(list(h.point), np.float32)))
         assert np.array_equal(bits(got["normal"].cpu().numpy()[j]), bits(np.array(list(h.normal), np.float32)))
@@ -427,8 +434,6 @@ def test_object_group_of_different_meshes(ctx, oracle):
     # what is not defined
     with pytest.raises(mp.MinipathError):
         mp.ObjectGroup([group, teapot], [[0, 0, 0], [1, 0, 0]])       # groups do not nest
-    with pytest.raises(mp.MinipathError):
-        mp.ObjectGroup([teapot, mp.Sphere((0, 0, 0), 1.0, ctx)], [[0, 0, 0], [1, 0, 0]])
     with pytest.raises(mp.MinipathError):
         group.export()                                                # a group has no arrays of its own
     with pytest.raises(mp.MinipathError):

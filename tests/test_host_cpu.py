@@ -384,7 +384,7 @@ print("rc2", rc2)
 
 def test_object_group_host_side():
     """mp_scene_group without a GPU: counts are sums over the members, the box is the union of the translated boxes, the material
-    table covers the largest id any member uses; nesting, spheres and NULL members are refused; instances keep the object's counts."""
+    table covers the largest id any member uses; nesting is refused, a Sphere can be a member; instances keep the object's counts."""
     from tests import meshes
 
     a = mp.TriangleBvh.with_obj(TEAPOT)
@@ -407,8 +407,10 @@ def test_object_group_host_side():
         g.export()
     with pytest.raises(mp.MinipathError):
         mp.ObjectGroup([g, a], [[0, 0, 0], [1, 0, 0]])
+    gs = mp.ObjectGroup([a, mp.Sphere((0, 0.5, 0), 1.5)], [[0, 0, 0], [10, 0, 0]])  # the reference's other Object: a member too
+    assert gs.info().triangle_count == ia.triangle_count and gs.info().bbox_max[0] == np.float32(11.5)
     with pytest.raises(mp.MinipathError):
-        mp.ObjectGroup([a, mp.Sphere((0, 0, 0), 1.0)], [[0, 0, 0], [1, 0, 0]])
+        mp.Instances(mp.Sphere((0, 0, 0), 1.0), [[0, 0, 0]])  # instancing is for TriangleBvh objects
     with pytest.raises(ValueError):
         mp.ObjectGroup([a, b], [[0, 0, 0]])
     inst = mp.Instances(b, tr)

@@ -23,6 +23,8 @@ def run(cases, seed, ctx=None):
         pos, nrm, tex, tri = meshes.make(name)
         mat = (np.arange(tri.shape[0]) * 7 % 3).astype(np.uint32)  # three materials, interleaved
         scenes[name] = (mp.Scene(mp.TriangleBvh.build(pos, nrm, tex, tri, ctx, tri_material=mat)), po.Bvh.build(pos, nrm, tex, tri, tri_material=mat))
+    ball_def = ((0.3, 0.2, -0.1), 1.1)
+    ball = mp.Sphere(*ball_def, ctx)
     bad = 0
     for case in range(cases):
         if case and case % 500 == 0:
@@ -62,10 +64,14 @@ def run(cases, seed, ctx=None):
             names = [name] + [list(scenes)[int(rng.integers(len(scenes)))] for _ in range(int(rng.integers(1, 4)))]
             order = rng.permutation(len(names))
             names = [names[i] for i in order]
-            tr = (rng.normal(size=(len(names), 3)) * 3.0).astype(np.float32)
-            grp = mp.ObjectGroup([scenes[m][0].object for m in names], tr)
+            gm, om = [scenes[m][0].object for m in names], [scenes[m][1] for m in names]
+            if rng.random() < 0.4:   # ... and a Sphere among them
+                at_ = int(rng.integers(len(gm) + 1))
+                gm.insert(at_, ball); om.insert(at_, ball_def)
+            tr = (rng.normal(size=(len(gm), 3)) * 3.0).astype(np.float32)
+            grp = mp.ObjectGroup(gm, tr)
             grp.set_materials(table, sky)
-            use = mp.Scene(grp); ob.set_group([scenes[m][1] for m in names], tr)
+            use = mp.Scene(grp); ob.set_group(om, tr)
         else:
             ob.set_instances(np.zeros((0, 3), np.float32))
         po.lib().mpo_set_chunked_sum(1 if chunked else 0)
