@@ -111,6 +111,46 @@ def test_trace_synthetic_scenes(ctx, oracle, name):
     torch.cuda.synchronize()
 
 
+def test_trace_non_finite_and_extreme_rays(teapot, oracle, teapot_oracle_bvh):
+    """Rays no renderer produces but a caller of mp_trace_rays can hand over: zero-length directions (Ray::new divides 0 by 0:
+    NaN direction, NaN inverse), NaN / infinite origins and directions, directions of 1e-30 and 1e30 length, origins 1e30 away,
+    origins exactly on the scene box, denormal components.  The walk has no special cases for them: every comparison against a NaN
+    is false on the GPU as on the CPU, so (t, prim, u, v) still match the oracle bit for bit (and nothing hangs or faults)."""
+    rng = np.random.default_rng(99)
+    bmin, bmax = [np.asarray(x, np.float32) for x in teapot_oracle_bvh.bbox()]
+    o, d = meshes.random_rays(4096, 5, bmin, bmax)
+    n = o.shape[0]
+    nan, inf = np.float32(np.nan), np.float32(np.inf)
+    k = 0
+    def block(m):
+        nonlocal k
+        sl = slice(k, k + m); k += m
+        return sl
+    d[block(64)] = 0.0                                   # zero-length direction
+    d[block(64), rng.integers(0, 3, 64)] = nan           # one NaN component
+    o[block(64), rng.integers(0, 3, 64)] = nan
+    d[block(64), rng.integers(0, 3, 64)] = inf           # infinite direction component: the unit vector has a NaN and zeros
+    o[block(64), rng.integers(0, 3, 64)] = -inf
+    sl = block(128); d[sl] = d[sl] * np.float32(1e-30)   # tiny but normal length
+    sl = block(128); d[sl] = d[sl] * np.float32(1e-41)   # denormal components (length underflows towards 0)
+    sl = block(128); d[sl] = d[sl] * np.float32(1e30)    # the squared length overflows: norm = inf, direction 0 or NaN
+    sl = block(128); o[sl] = o[sl] + np.float32(1e30)    # origin far away
+    sl = block(128); o[sl, 0] = bmin[0]                  # origin exactly on the box's faces
+    sl = block(128); o[sl, 1] = bmax[1]; d[sl, 1] = 0.0  # ... sliding along one
+    sl = block(64); o[sl] = np.float32(1e-42)            # denormal origin
+    assert k <= n
+    got, exp = _trace_both(teapot, teapot_oracle_bvh, o, d, full=True)
+    _assert_hits_equal(got, exp)
+    hit = exp[1] != 0xFFFFFFFF
+    assert 200 < hit.sum() < n  # the ordinary rays among them still hit
+    # misses report t = f32::MAX and zeroed records
+    assert np.all(got["t"][~hit] == np.finfo(np.float32).max) and not got["normal"][~hit].any() and not got["point"][~hit].any()
+    for i in np.flatnonzero(hit)[:300]:
+        h = teapot_oracle_bvh.intersect(oracle.ray_new(o[i], d[i]))
+        assert np.array_equal(bits(got["point"][i]), bits(np.array(list(h.point), np.float32)))
+        assert np.array_equal(bits(got["normal"][i]), bits(np.array(list(h.normal), np.float32)))
+
+
 def test_trace_edge_sizes(teapot, teapot_oracle_bvh):
     """n = 0, 1, 63, 64, 65 rays (partial wave queues)."""
     import torch
