@@ -226,18 +226,23 @@ const char *mp_scene_material_name(const mp_scene *scene, uint32_t id);
 /* scene/primitives.rs:10-56 Sphere as the scene's Object (analytic intersection, no BVH).  ctx may be NULL (host-only). */
 int mp_scene_sphere(mp_ctx *ctx, const float center[3], float radius, mp_scene **out);
 /* BUILD-DEFINED Object (scene/mod.rs:7-10 `trait Object`; the reference's Scene holds ONE object and has no transforms): a
- * top-level list of n members {object, translation} (objects: n TriangleBvh or Sphere scenes of this context -- the reference's
- * two Object implementations -- repeats allowed, groups do not nest; translations: n*3 floats, copied).  intersect = for every member in order the member's own intersect with the ray moved into
- * the member's frame (origin - translation; direction and t unchanged), closest wins with a strict `<` (the first member keeps
- * ties); HitRecord.point = point_at(t) of the world ray, normal / tex / material id are the member's; mp_hits_soa.d_instance =
- * index of the member that was hit, prim = triangle index inside that member (0, material 0 and texture_coords 0 for a Sphere
- * member, primitives.rs:40-46).  The group has ONE material table indexed by the
- * members' material ids (initially the first member's, padded with the default material; mp_scene_set_materials replaces it)
- * and the first member's sky radiance.  get_bounding_box = union of the translated boxes; mp_scene_info counts are sums over the
+ * top-level list of n members {object, rigid transform}.  objects: n TriangleBvh or Sphere scenes of this context (the
+ * reference's two Object implementations), repeats allowed, groups do not nest.  Transform of member k: world = q_k * local +
+ * t_k with translations = n*3 floats and rotations = n*4 floats, unit quaternions (i, j, k, w) as nalgebra stores them (the type
+ * of the reference's camera isometry, camera.rs:9-19), or NULL for translations only; both copied.
+ * intersect = for every member in order the member's own intersect with the ray moved into the member's frame -- origin -
+ * translation, then origin and direction through the inverse rotation; the direction is not re-normalised, so t stays the
+ * world ray's -- closest wins with a strict `<` (the first member keeps ties).  HitRecord.point = point_at(t) of the world ray,
+ * normal = q * the member's normal, tex / material id are the member's; mp_hits_soa.d_instance = index of the member that was
+ * hit, prim = triangle index inside that member (0, material 0 and texture_coords 0 for a Sphere member, primitives.rs:40-46).
+ * The group has ONE material table indexed by the members' material ids (initially the first member's, padded with the default
+ * material; mp_scene_set_materials replaces it) and the first member's sky radiance.  get_bounding_box = union of the members'
+ * boxes in the world frame (rotated member: the box of its box's rotated corners); mp_scene_info counts are sums over the
  * members.  The group SHARES its members' device arrays: they must outlive it.  Rendered by the 8-lane-group traversal (every
  * kernel but the staged MP_FLAG_WAVEFRONT pipeline); defined operation by operation in oracle/minipath_oracle.c
  * (bvh_intersect_impl). */
-int mp_scene_group(mp_ctx *ctx, const mp_scene *const *objects, const float *translations, uint32_t n, mp_scene **out);
+int mp_scene_group(mp_ctx *ctx, const mp_scene *const *objects, const float *rotations, const float *translations, uint32_t n,
+                   mp_scene **out);
 /* n members that are all `object` (instancing): as mp_scene_group, except that mp_scene_info reports the object's own counts and
  * mp_scene_export exports the object's arrays. */
 int mp_scene_instances(mp_ctx *ctx, const mp_scene *object, const float *translations, uint32_t n, mp_scene **out);

@@ -174,7 +174,7 @@ SIGNATURES = {
     "mp_scene_material_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
     "mp_scene_sphere": (C.c_int, [C.c_void_p, _f3, C.c_float, C.POINTER(C.c_void_p)]),
     "mp_scene_instances": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
-    "mp_scene_group": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "mp_scene_group": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
     "mp_scene_destroy": (None, [C.c_void_p]),
     "mp_scene_info_get": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
     "mp_scene_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

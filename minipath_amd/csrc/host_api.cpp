@@ -728,9 +728,19 @@ int mp_scene_from_arrays(mp_ctx* ctx, const mp_bvh_desc* desc, mp_scene** out) {
 
 namespace {
 
-// {object, translation} x n behind one Object (include/minipath_hip.h: mp_scene_group).  The group borrows its members' device
+// UnitQuaternion * Vector3, the operation order of the oracle and of the device code (kernels.hip: quat_rotate)
+void quat_rotate_host(const float q[4], const float v[3], float out[3]) {
+    const float tx = (q[1] * v[2] - q[2] * v[1]) * 2.0f, ty = (q[2] * v[0] - q[0] * v[2]) * 2.0f, tz = (q[0] * v[1] - q[1] * v[0]) * 2.0f;
+    const float cx = q[1] * tz - q[2] * ty, cy = q[2] * tx - q[0] * tz, cz = q[0] * ty - q[1] * tx;
+    out[0] = tx * q[3] + cx + v[0];
+    out[1] = ty * q[3] + cy + v[1];
+    out[2] = tz * q[3] + cz + v[2];
+}
+
+// {object, rigid transform} x n behind one Object (include/minipath_hip.h: mp_scene_group).  The group borrows its members' device
 // arrays; it owns the descriptor array and its own material table.
-int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* translations, uint32_t n, bool one_object, mp_scene** out) {
+int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* rotations, const float* translations, uint32_t n,
+               bool one_object, mp_scene** out) {
     if (!objects || !translations || !out || n == 0) return fail(MP_ERR_INVALID, "bad argument");
     if (n > (1u << 20)) return fail(MP_ERR_INVALID, "too many members");
     for (uint32_t i = 0; i < n; i++) {
@@ -763,15 +773,29 @@ int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* transla
         s->material_count = std::max(s->material_count, o->material_count);
         s->dev.stack_cap = std::max(s->dev.stack_cap, o->dev.stack_cap);
     }
-    for (int k = 0; k < 3; k++) {  // get_bounding_box: union of the translated boxes
-        float mn = 0, mx = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            const float a = objects[i]->host.bbox.mn[k] + translations[3 * i + k], b = objects[i]->host.bbox.mx[k] + translations[3 * i + k];
-            mn = i ? std::fmin(mn, a) : a;
-            mx = i ? std::fmax(mx, b) : b;
+    // get_bounding_box: union of the members' boxes in the world frame (a rotated member: the box of its box's eight rotated corners)
+    for (uint32_t i = 0; i < n; i++) {
+        const Box3& ob = objects[i]->host.bbox;
+        float lo[3], hi[3];
+        if (rotations) {
+            const float* q = rotations + 4 * static_cast<size_t>(i);
+            for (int c = 0; c < 8; c++) {
+                const float v[3] = {(c & 1) ? ob.mx[0] : ob.mn[0], (c & 2) ? ob.mx[1] : ob.mn[1], (c & 4) ? ob.mx[2] : ob.mn[2]};
+                float w[3];
+                quat_rotate_host(q, v, w);
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = c ? std::fmin(lo[k], w[k]) : w[k];
+                    hi[k] = c ? std::fmax(hi[k], w[k]) : w[k];
+                }
+            }
+        } else {
+            for (int k = 0; k < 3; k++) { lo[k] = ob.mn[k]; hi[k] = ob.mx[k]; }
         }
-        s->host.bbox.mn[k] = mn;
-        s->host.bbox.mx[k] = mx;
+        for (int k = 0; k < 3; k++) {
+            const float a = lo[k] + translations[3 * i + k], b = hi[k] + translations[3 * i + k];
+            s->host.bbox.mn[k] = i ? std::fmin(s->host.bbox.mn[k], a) : a;
+            s->host.bbox.mx[k] = i ? std::fmax(s->host.bbox.mx[k], b) : b;
+        }
     }
     // material table of the group: the first member's, padded with the default material up to the largest id any member uses
     s->materials = objects[0]->materials;
@@ -792,6 +816,10 @@ int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* transla
             for (int k = 0; k < 3; k++) {
                 o.pre_min[k] = d.pre_min[k]; o.pre_max[k] = d.pre_max[k]; o.t[k] = translations[3 * i + k];
                 o.sphere_center[k] = d.sphere_center[k];
+            }
+            if (rotations) {
+                for (int k = 0; k < 4; k++) o.q[k] = rotations[4 * static_cast<size_t>(i) + k];
+                o.rotated = 1u;
             }
         }
         MP_HIP(hipMalloc(&s->d_inst, desc.size() * sizeof(DevObject)));
@@ -814,15 +842,16 @@ int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* transla
 
 }  // namespace
 
-int mp_scene_group(mp_ctx* ctx, const mp_scene* const* objects, const float* translations, uint32_t n, mp_scene** out) {
-    return guarded([&]() -> int { return make_group(ctx, objects, translations, n, false, out); });
+int mp_scene_group(mp_ctx* ctx, const mp_scene* const* objects, const float* rotations, const float* translations, uint32_t n,
+                   mp_scene** out) {
+    return guarded([&]() -> int { return make_group(ctx, objects, rotations, translations, n, false, out); });
 }
 
 int mp_scene_instances(mp_ctx* ctx, const mp_scene* object, const float* translations, uint32_t n, mp_scene** out) {
     return guarded([&]() -> int {
     if (!object || n == 0 || n > (1u << 20)) return fail(MP_ERR_INVALID, "bad argument");
     std::vector<const mp_scene*> objs(n, object);
-    return make_group(ctx, objs.data(), translations, n, true, out);
+    return make_group(ctx, objs.data(), nullptr, translations, n, true, out);
     });
 }
 

@@ -389,11 +389,28 @@ __device__ __forceinline__ void object_scene(const DevScene& sc, uint32_t k, Dev
     sk.kind = o.kind; sk.sphere_radius = o.sphere_radius;
     for (int i = 0; i < 3; i++) { sk.pre_min[i] = o.pre_min[i]; sk.pre_max[i] = o.pre_max[i]; sk.sphere_center[i] = o.sphere_center[i]; }
 }
-// ... and the ray in member k's frame (origin - translation; direction, hence t, unchanged)
+// UnitQuaternion * Vector3 as the oracle (and nalgebra) evaluate it: t = 2 * (qv x v); v' = t * w + (qv x t) + v, unfused
+__device__ __forceinline__ void quat_rotate(float qi, float qj, float qk, float qw, float vx, float vy, float vz, float& ox,
+                                            float& oy, float& oz) {
+    const float tx = (qj * vz - qk * vy) * 2.0f, ty = (qk * vx - qi * vz) * 2.0f, tz = (qi * vy - qj * vx) * 2.0f;
+    const float cx = qj * tz - qk * ty, cy = qk * tx - qi * tz, cz = qi * ty - qj * tx;
+    ox = tx * qw + cx + vx; oy = ty * qw + cy + vy; oz = tz * qw + cz + vz;
+}
+// ... and the ray in member k's frame: origin - translation, then (rotated members) origin and direction through the inverse
+// rotation; the direction is not re-normalised (t stays the world ray's), inv_direction by Ray::new's rule (geometry/mod.rs:49-53)
 __device__ __forceinline__ void object_ray(const DevScene& sc, uint32_t k, const Ray& r, Ray& rk) {
-    const float* t = sc.objects[k].t;
+    const DevObject& o = sc.objects[k];
     rk = r;
-    rk.ox = r.ox - t[0]; rk.oy = r.oy - t[1]; rk.oz = r.oz - t[2];
+    rk.ox = r.ox - o.t[0]; rk.oy = r.oy - o.t[1]; rk.oz = r.oz - o.t[2];
+    if (o.rotated) {
+        const float qi = -o.q[0], qj = -o.q[1], qk = -o.q[2], qw = o.q[3];
+        const float vx = rk.ox, vy = rk.oy, vz = rk.oz;
+        quat_rotate(qi, qj, qk, qw, vx, vy, vz, rk.ox, rk.oy, rk.oz);
+        quat_rotate(qi, qj, qk, qw, r.dx, r.dy, r.dz, rk.dx, rk.dy, rk.dz);
+        rk.ix = (rk.dx == 0.0f) ? INFINITY : 1.0f / rk.dx;
+        rk.iy = (rk.dy == 0.0f) ? INFINITY : 1.0f / rk.dy;
+        rk.iz = (rk.dz == 0.0f) ? INFINITY : 1.0f / rk.dz;
+    }
 }
 
 struct GroupHit {
@@ -449,14 +466,18 @@ __device__ __forceinline__ uint32_t object_normal(const DevScene& sc, uint32_t i
                                                   float n[3]) {
     DevScene so;
     object_scene(sc, inst, so);
+    uint32_t mat = 0u;
     if (so.kind == 1u) {
         Ray rk;
         object_ray(sc, inst, r, rk);
         float t;
         sphere_intersect(so, rk, t, n);
-        return 0u;
+    } else {
+        mat = resolve_normal(so, prim, u, v, n);
     }
-    return resolve_normal(so, prim, u, v, n);
+    const DevObject& o = sc.objects[inst];
+    if (o.rotated) quat_rotate(o.q[0], o.q[1], o.q[2], o.q[3], n[0], n[1], n[2], n[0], n[1], n[2]);  // back into the world frame
+    return mat;
 }
 
 // ---- fused tile render: Worker::render_tile (worker.rs:32-49) for a list of tiles -----------------------------

@@ -74,7 +74,7 @@ int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err);
 // shade     : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) material(u32 bits) pad.  48 B per triangle slot.
 // vidx/vtex : for the full HitRecord (texture_coords).
 // One member {object, translation} of a build-defined object group (mp_scene_group / mp_scene_instances): the member's own
-// traversal arrays (borrowed from its scene) or its sphere, and the translation that places it.  112 bytes.
+// traversal arrays (borrowed from its scene) or its sphere, and the rigid transform that places it.  128 bytes.
 struct DevObject {
     const float* shade;
     const float* nodes_aos;
@@ -88,9 +88,11 @@ struct DevObject {
     uint32_t kind;              // 0 = TriangleBvh, 1 = Sphere (scene/primitives.rs:10-13)
     float sphere_center[3];
     float sphere_radius;
-    uint32_t pad[2];
+    float q[4];                 // rotation (unit quaternion i, j, k, w): world = q * local + t
+    uint32_t rotated;           // 0 = translation only (q is not applied: the ray keeps its exact direction)
+    uint32_t pad;
 };
-static_assert(sizeof(DevObject) == 112, "DevObject layout");
+static_assert(sizeof(DevObject) == 128, "DevObject layout");
 
 struct DevScene {
     uint32_t kind = 0;               // 0 = TriangleBvh, 1 = Sphere (scene/primitives.rs:10-13)

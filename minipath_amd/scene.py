@@ -204,17 +204,24 @@ class ObjectGroup(TriangleBvh):
     context (mp_scene_group); hits carry the member index (`instance`) and the triangle index inside that member.  Shares the members'
     device arrays: keeps references to them."""
 
-    def __init__(self, objects, translations):
+    def __init__(self, objects, translations, rotations=None):
+        """rotations: optional unit quaternions (i, j, k, w), one per member: world = q * local + translation."""
         objects = list(objects)
         t = np.ascontiguousarray(translations, np.float32).reshape(-1, 3)
         if len(objects) != t.shape[0] or not objects:
             raise ValueError("one translation per member")
+        q = None
+        if rotations is not None:
+            q = np.ascontiguousarray(rotations, np.float32).reshape(-1, 4)
+            if q.shape[0] != t.shape[0]:
+                raise ValueError("one rotation per member")
         ctx = objects[0].ctx
         arr = (C.c_void_p * len(objects))(*[o.handle for o in objects])
         h = C.c_void_p()
-        _lib.check(_lib.lib().mp_scene_group(ctx.handle if ctx else None, arr, t.ctypes.data, len(objects), C.byref(h)))
+        _lib.check(_lib.lib().mp_scene_group(ctx.handle if ctx else None, arr, q.ctypes.data if q is not None else None, t.ctypes.data,
+                                             len(objects), C.byref(h)))
         super().__init__(h, ctx)
-        self.objects, self.translations = objects, t
+        self.objects, self.translations, self.rotations = objects, t, q
 
     def close(self):
         super().close()  # before the members it borrows from

@@ -549,6 +549,7 @@ struct mpo_bvh {
     uint32_t n_inst; float *inst_t;
     const struct mpo_bvh **inst_obj; /* member objects of a group (NULL: every member is this BVH) */
     float *inst_sph;                  /* group: 4 floats per member {center, radius}; radius < 0 = the member is a BVH */
+    float *inst_q;                    /* group: unit quaternion (i, j, k, w) per member, NULL = no member is rotated */
 };
 
 typedef struct { float mn[3], mx[3]; } box3;
@@ -956,7 +957,7 @@ uint32_t mpo_bvh_material_count(const mpo_bvh *b) {
 
 void mpo_bvh_free(mpo_bvh *b) {
     if (!b) return;
-    free(b->inner); free(b->packets); free(b->shading); free(b->vnormal); free(b->vtex); free(b->material); free(b->mats); free(b->inst_t); free(b->inst_obj); free(b->inst_sph);
+    free(b->inner); free(b->packets); free(b->shading); free(b->vnormal); free(b->vtex); free(b->material); free(b->mats); free(b->inst_t); free(b->inst_obj); free(b->inst_sph); free(b->inst_q);
     free(b);
 }
 
@@ -1241,6 +1242,15 @@ static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache
     for (uint32_t k = 0; k < b->n_inst; k++) {
         mpo_ray r2 = *ray;
         for (int i = 0; i < 3; i++) r2.o[i] = ray->o[i] - b->inst_t[3 * k + i];
+        const float *q = b->inst_q ? &b->inst_q[4 * k] : NULL;
+        if (q) { /* world = q * local + translation: the ray goes through the inverse rotation; the direction is NOT re-normalised
+                  * (t keeps the world ray's scale), inv_direction by Ray::new's rule (geometry/mod.rs:49-53) */
+            const float qc[4] = {-q[0], -q[1], -q[2], q[3]};
+            float v[3] = {r2.o[0], r2.o[1], r2.o[2]};
+            quat_rotate(qc, v, r2.o);
+            quat_rotate(qc, ray->d, r2.d);
+            for (int i = 0; i < 3; i++) r2.inv[i] = (r2.d[i] == 0.0f) ? INFINITY : 1.0f / r2.d[i];
+        }
         mpo_hit h;
         if (b->inst_sph && b->inst_sph[4 * k + 3] >= 0.0f) { /* a Sphere member (primitives.rs:16-48): material 0, tex = origin */
             mpo_sphere_intersect(&b->inst_sph[4 * k], b->inst_sph[4 * k + 3], &r2, &h);
@@ -1248,7 +1258,11 @@ static void bvh_intersect_impl(const mpo_bvh *b, const mpo_ray *ray, stack_cache
         } else
             bvh_intersect_one(b->inst_obj ? b->inst_obj[k] : b, &r2, st, &h, cnt);
         if (cnt) cnt->rays--; /* one Object::intersect call of the scene's object, however many members it holds */
-        if (h.hit && h.t < best.t) { best = h; best.instance = k; }
+        if (h.hit && h.t < best.t) {
+            best = h;
+            best.instance = k;
+            if (q) quat_rotate(q, h.normal, best.normal); /* the normal back into the world frame */
+        }
     }
     if (cnt) cnt->rays++;
     if (best.hit) mpo_ray_point_at(ray, best.t, best.point);
@@ -1274,14 +1288,27 @@ int mpo_bvh_set_group(mpo_bvh *b, const mpo_bvh *const *objects, const float *sp
     return 1;
 }
 
+int mpo_bvh_set_group_rotations(mpo_bvh *b, const float *quaternions) {
+    if (!b) return 0;
+    free(b->inst_q);
+    b->inst_q = NULL;
+    if (quaternions && b->n_inst) {
+        b->inst_q = malloc((size_t)b->n_inst * 4 * sizeof(float));
+        memcpy(b->inst_q, quaternions, (size_t)b->n_inst * 4 * sizeof(float));
+    }
+    return 1;
+}
+
 int mpo_bvh_set_instances(mpo_bvh *b, const float *translations, uint32_t n) {
     if (!b || (n && !translations)) return 0;
     free(b->inst_t);
     free(b->inst_obj);
     free(b->inst_sph);
+    free(b->inst_q);
     b->inst_t = NULL;
     b->inst_obj = NULL;
     b->inst_sph = NULL;
+    b->inst_q = NULL;
     b->n_inst = n;
     if (n) {
         b->inst_t = malloc((size_t)n * 3 * sizeof(float));

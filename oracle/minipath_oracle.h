@@ -179,6 +179,10 @@ int mpo_bvh_set_instances(mpo_bvh *b, const float *translations, uint32_t n);
  * b is the container: its material table and sky apply, its own triangles are only reachable through members that name it.  The
  * members must outlive b's use. */
 int mpo_bvh_set_group(mpo_bvh *b, const mpo_bvh *const *objects, const float *spheres, const float *translations, uint32_t n);
+/* ... and a rotation per member of the current group (n_members * 4 floats, unit quaternions (i, j, k, w) as nalgebra stores
+ * them; NULL = none): world = q * local + translation.  The ray enters a member's frame as q^-1 * (origin - translation),
+ * q^-1 * direction (not re-normalised: t stays the world ray's), the hit normal leaves it as q * normal. */
+int mpo_bvh_set_group_rotations(mpo_bvh *b, const float *quaternions);
 void mpo_bvh_free(mpo_bvh *b);
 uint32_t mpo_bvh_root(const mpo_bvh *b);
 void mpo_bvh_bbox(const mpo_bvh *b, float bmin[3], float bmax[3]);

@@ -161,6 +161,8 @@ def lib() -> C.CDLL:
     L.mpo_bvh_set_instances.restype = C.c_int
     L.mpo_bvh_set_group.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), f32p, f32p, C.c_uint32]
     L.mpo_bvh_set_group.restype = C.c_int
+    L.mpo_bvh_set_group_rotations.argtypes = [C.c_void_p, f32p]
+    L.mpo_bvh_set_group_rotations.restype = C.c_int
     L.mpo_trace_rays_inst.argtypes = [C.c_void_p] + [f32p] * 6 + [C.c_uint64, f32p, u32p, f32p, f32p, u32p]
     L.mpo_seed_mix.argtypes = [C.c_uint64]
     L.mpo_seed_mix.restype = C.c_uint64
@@ -342,7 +344,7 @@ class Bvh:
         if not lib().mpo_bvh_set_instances(self.h, _f32p(t) if t.shape[0] else None, t.shape[0]):
             raise RuntimeError("set_instances failed")
 
-    def set_group(self, objects, translations) -> None:
+    def set_group(self, objects, translations, rotations=None) -> None:
         """BUILD-DEFINED Object: members {objects[k], translation k}; a member is a Bvh or a sphere given as (center, radius).
         This BVH is the container (its materials and sky apply).  Keeps references to the members."""
         t = np.ascontiguousarray(translations, np.float32).reshape(-1, 3)
@@ -356,6 +358,10 @@ class Bvh:
         if len(objects) != t.shape[0] or not lib().mpo_bvh_set_group(self.h, arr, _f32p(sph) if has_sphere else None, _f32p(t), t.shape[0]):
             raise RuntimeError("set_group failed")
         self._members = objects
+        if rotations is not None:
+            q = np.ascontiguousarray(rotations, np.float32).reshape(-1, 4)
+            if q.shape[0] != t.shape[0] or not lib().mpo_bvh_set_group_rotations(self.h, _f32p(q)):
+                raise RuntimeError("set_group rotations failed")
 
     def trace_inst(self, o: np.ndarray, d: np.ndarray):
         """trace() plus the instance index of every hit."""

@@ -446,6 +446,91 @@ def test_object_group_of_different_meshes(ctx, oracle):
     assert np.array_equal(bits(x), bits(y))
 
 
+def _unit_quaternions(rng, n):
+    """Random rotations as nalgebra stores them (i, j, k, w), normalised in f32; the first one is the exact identity."""
+    q = rng.standard_normal((n, 4)).astype(np.float32)
+    q /= np.sqrt((q.astype(np.float64) ** 2).sum(axis=1, keepdims=True)).astype(np.float32)
+    q[0] = (0.0, 0.0, 0.0, 1.0)
+    return q.astype(np.float32)
+
+
+def test_object_group_with_rotated_members(ctx, oracle):
+    """Members placed by a rigid transform (rotation + translation, the Isometry3 of the reference's camera): world = q * local + t.
+    The ray enters a member's frame through the inverse rotation without re-normalising its direction, the normal comes back
+    through q; quaternion products are evaluated in the oracle's operation order on the device.  Full hit records (world-space
+    normals and points), frames and paths == oracle, bit for bit; an identity quaternion member == the same member without
+    rotations where the arithmetic is the same, and a 90-degree turn about y maps a hit's normal as expected."""
+    import ctypes as C
+
+    import torch
+
+    rng = np.random.default_rng(17)
+    teapot = mp.TriangleBvh.with_obj(TEAPOT, ctx)
+    pos, nrm, tex, tri = meshes.make("soup_300")
+    soup = mp.TriangleBvh.build(pos, nrm, tex, tri, ctx)
+    ball = mp.Sphere((0.4, 0.0, 0.0), 1.0, ctx)
+    o_teapot, o_soup = oracle.Bvh.from_obj(TEAPOT), oracle.Bvh.build(pos, nrm, tex, tri)
+    gpu = [teapot, teapot, soup, ball, soup]
+    tr = np.array([[0, 0, 0], [7.0, 0.5, -2.0], [-5.5, 2.0, 1.0], [0.0, 5.0, -1.0], [3.0, 4.5, 2.5]], np.float32)
+    q = _unit_quaternions(rng, 5)
+    group = mp.ObjectGroup(gpu, tr, rotations=q)
+    scene = mp.Scene(group)
+    box = oracle.Bvh.from_obj(TEAPOT)
+    box.set_group([box, o_teapot, o_soup, ((0.4, 0.0, 0.0), 1.0), o_soup], tr, rotations=q)
+    i = group.info()
+    lo, hi = np.array(list(i.bbox_min), np.float32), np.array(list(i.bbox_max), np.float32)
+    o, d = meshes.random_rays(40000, 23, lo, hi)
+    got = group.intersect(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda(), full=True)
+    torch.cuda.synchronize()
+    t, prim, u, v, which = box.trace_inst(o, d)
+    assert np.array_equal(got["prim"].cpu().numpy().view(np.uint32), prim)
+    assert np.array_equal(got["instance"].cpu().numpy().view(np.uint32), which)
+    for k, e in (("t", t), ("u", u), ("v", v)):
+        assert np.array_equal(bits(got[k].cpu().numpy()), bits(e)), k
+    hit = prim != 0xFFFFFFFF
+    assert sorted(np.unique(which[hit]).tolist()) == [0, 1, 2, 3, 4] and hit.mean() > 0.1
+    gn, gp_ = got["normal"].cpu().numpy(), got["point"].cpu().numpy()
+    for j in np.flatnonzero(hit)[:: max(1, int(hit.sum()) // 500)]:
+        h = box.intersect(oracle.ray_new(o[j], d[j]))
+        assert np.array_equal(bits(gn[j]), bits(np.array(list(h.normal), np.float32))), (j, which[j])
+        assert np.array_equal(bits(gp_[j]), bits(np.array(list(h.point), np.float32)))
+    assert np.allclose(np.linalg.norm(gn[hit], axis=1), 1.0, atol=1e-5)  # rotations keep normals unit up to rounding
+    # every hit lies inside the group's box (rotated corners + translation), up to rounding
+    assert np.all(gp_[hit] >= lo - 1e-3) and np.all(gp_[hit] <= hi + 1e-3)
+    # frames
+    eye, at = (2.0, 6.0, 21.0), (0.5, 2.5, -0.5)
+    oc = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(oc))
+    oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(*eye), oracle.vec3(*at), oracle.vec3(0, 1, 0))
+    cam = mp.Camera.default().look_at(eye, at, (0, 1, 0))
+    res = (160, 112)
+    osmp = oracle.build_sampler(oc, *res)
+    of, _, _, _, _ = box.render_image_mt(osmp, res[0], res[1], 5, 8, 32, 8)
+    a, seg = _render(scene, cam, mp.RenderSettings(32, 5, res, seed=8))
+    assert np.array_equal(bits(a), bits(of)) and seg == res[0] * res[1] * 5 and (of[..., 3] > 0).mean() > 0.1
+    pf, _, _, pseg = box.render_image_paths_mt(osmp, res[0], res[1], 9, 8, 5, 32, 8)
+    b, gseg = _render(scene, cam, mp.RenderSettings(32, 9, res, seed=8, max_depth=5))
+    assert np.array_equal(bits(b), bits(pf)) and gseg == pseg
+    # a quarter turn about +y (q = (0, sin 45, 0, cos 45)): local +z faces world +x
+    s45 = np.float32(np.sqrt(0.5))
+    turned = mp.ObjectGroup([soup], [[0, 0, 0]], rotations=[[0, s45, 0, s45]])
+    plain = mp.ObjectGroup([soup], [[0, 0, 0]])
+    bi = soup.info()
+    ro, rd = meshes.random_rays(4000, 31, np.array(list(bi.bbox_min)), np.array(list(bi.bbox_max)))   # rays in the local frame
+    turn = lambda a: np.ascontiguousarray(np.stack([a[:, 2], a[:, 1], -a[:, 0]], axis=1))            # ... and the same rays turned
+    hp = plain.intersect(torch.from_numpy(ro).cuda(), torch.from_numpy(rd).cuda(), full=True)
+    ht = turned.intersect(torch.from_numpy(turn(ro)).cuda(), torch.from_numpy(turn(rd)).cuda(), full=True)
+    torch.cuda.synchronize()
+    pp, pt = hp["prim"].cpu().numpy(), ht["prim"].cpu().numpy()
+    same = (pp == pt) & (pp != -1)
+    assert (pp != -1).sum() > 150 and same.sum() > 0.98 * (pp != -1).sum()  # sqrt(0.5) is rounded: a few grazing rays may differ
+    assert np.allclose(hp["t"].cpu().numpy()[same], ht["t"].cpu().numpy()[same], rtol=1e-4, atol=1e-4)
+    assert np.allclose(turn(hp["normal"].cpu().numpy()[same]), ht["normal"].cpu().numpy()[same], atol=1e-4)
+    assert np.allclose(turn(hp["point"].cpu().numpy()[same]), ht["point"].cpu().numpy()[same], atol=1e-3)
+    with pytest.raises(ValueError):
+        mp.ObjectGroup([soup, soup], [[0, 0, 0], [1, 0, 0]], rotations=[[0, 0, 0, 1]])
+
+
 def test_instances_keep_the_material_table_they_were_made_with(ctx, oracle):
     """Regression (found by tools/fuzz_gpu.py): an instanced scene shares its object's material table by reference; a later
     mp_scene_set_materials on the object gives the OBJECT a new table and must neither free the old one under the instanced scene

@@ -440,6 +440,37 @@ def test_oracle_group_is_the_members_traced_one_by_one():
         better = (pk != 0xFFFFFFFF) & (tk < bt)
         bt[better], bp[better], bu[better], bv[better], bw[better] = tk[better], pk[better], uk[better], vk[better], j
     hit = bp != 0xFFFFFFFF
+    # rotated members: the definition again, with the quaternion products of nalgebra spelled out in numpy f32
+    def rot(qv, v):
+        qv = qv.astype(np.float32); v = v.astype(np.float32)
+        def cross(a, b):
+            return np.stack([a[..., 1] * b[..., 2] - a[..., 2] * b[..., 1], a[..., 2] * b[..., 0] - a[..., 0] * b[..., 2],
+                             a[..., 0] * b[..., 1] - a[..., 1] * b[..., 0]], axis=-1).astype(np.float32)
+        tq = (cross(qv[:3][None, :], v) * np.float32(2.0)).astype(np.float32)
+        c = cross(qv[:3][None, :], tq)
+        return ((tq * qv[3]).astype(np.float32) + c + v).astype(np.float32)
+    rng = np.random.default_rng(4)
+    q = rng.standard_normal((len(members), 4)).astype(np.float32)
+    q = (q / np.linalg.norm(q.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    box.set_group([box if k == 0 else objs[k] for k in members], tr, rotations=q)
+    t2, prim2, u2, v2, which2 = box.trace_inst(o, d)
+    dn = np.stack([po.ray_new(o[i], d[i]).d[:] for i in range(600)]).astype(np.float32)  # Ray::new's unit directions
+    qc = q * np.array([-1, -1, -1, 1], np.float32)
+    sel = np.arange(600)
+    bt2 = np.full(600, np.finfo(np.float32).max, np.float32); bp2 = np.full(600, 0xFFFFFFFF, np.uint32); bw2 = np.zeros(600, np.uint32)
+    for j, k in enumerate(members):
+        ol = rot(qc[j], (o[sel] - tr[j]).astype(np.float32)); dl = rot(qc[j], dn)
+        for i in range(600):   # the member's own intersect on the un-normalised local ray
+            r = po.Ray()
+            for c in range(3):
+                r.o[c], r.d[c] = float(ol[i, c]), float(dl[i, c])
+                r.inv[c] = float(np.float32(np.inf)) if dl[i, c] == 0 else float(np.float32(1.0) / dl[i, c])
+            h = objs[k].intersect(r)
+            if h.hit and np.float32(h.t) < bt2[i]:
+                bt2[i], bp2[i], bw2[i] = h.t, h.prim, j
+    assert np.array_equal(prim2[:600], bp2) and np.array_equal(t2[:600].view(np.uint32), bt2.view(np.uint32))
+    h2 = bp2 != 0xFFFFFFFF
+    assert h2.sum() > 20 and np.array_equal(which2[:600][h2], bw2[h2])
     assert hit.sum() > 500 and set(np.unique(bw[hit]).tolist()) >= {0, 1, 2, 4} and 3 not in set(bw[hit].tolist())
     assert np.array_equal(prim, bp) and np.array_equal(which[hit], bw[hit])
     for a, b in ((t, bt), (u, bu), (v, bv)):

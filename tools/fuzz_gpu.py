@@ -69,9 +69,15 @@ def run(cases, seed, ctx=None):
                 at_ = int(rng.integers(len(gm) + 1))
                 gm.insert(at_, ball); om.insert(at_, ball_def)
             tr = (rng.normal(size=(len(gm), 3)) * 3.0).astype(np.float32)
-            grp = mp.ObjectGroup(gm, tr)
+            rot = None
+            if rng.random() < 0.5:   # ... placed by rigid transforms (some of them exact identities / axis turns)
+                rot = rng.standard_normal((len(gm), 4)).astype(np.float32)
+                rot = (rot / np.linalg.norm(rot.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+                rot[0] = (0, 0, 0, 1)
+                if len(gm) > 2: rot[2] = (0, np.float32(np.sqrt(0.5)), 0, np.float32(np.sqrt(0.5)))
+            grp = mp.ObjectGroup(gm, tr, rotations=rot)
             grp.set_materials(table, sky)
-            use = mp.Scene(grp); ob.set_group(om, tr)
+            use = mp.Scene(grp); ob.set_group(om, tr, rotations=rot)
         else:
             ob.set_instances(np.zeros((0, 3), np.float32))
         po.lib().mpo_set_chunked_sum(1 if chunked else 0)
