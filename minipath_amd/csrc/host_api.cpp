@@ -182,6 +182,10 @@ struct mp_scene {
     uint64_t device_bytes = 0;
 };
 
+#ifndef MP_RENDER_SLOTS
+#define MP_RENDER_SLOTS 3  // batches of tiles in flight per render() worker (measured on the metric's frame: 2 -> 50.4-51.1 ms, 3 -> 49.1-49.5, 4 -> 49.4-49.7; bare launch 48.8)
+#endif
+
 namespace {
 
 struct DeviceGuard {
@@ -1239,9 +1243,9 @@ void render_worker(mp_render* r, size_t wi) {
     const uint32_t ts = st.tile_size;
     const size_t per_tile = static_cast<size_t>(ts) * ts * 4;  // floats (and u8 bytes) per tile slot
     // A batch is what one launch renders: enough work units to fill every CU a few times over, small enough that the tile
-    // callbacks keep flowing (the reference hands out one tile per worker thread).  Two batches are in flight: while the GPU
-    // renders and quantises (color_to_image) batch k+1 and copies it to pinned host memory, this thread files batch k's rows
-    // into the image and runs its callbacks.
+    // callbacks keep flowing (the reference hands out one tile per worker thread).  kSlots batches are in flight, each on its own
+    // stream: while the GPU renders and quantises (color_to_image) the later ones and copies them to pinned host memory (the tail of
+    // one launch overlaps the start of the next), this thread files the oldest batch's rows into the image and runs its callbacks.
     const size_t batch = r->batch;
     int my_status = MP_OK;  // this worker's view; the shared status records the first error of any worker
     auto set_error = [&](int code, const std::string& msg) {
@@ -1254,7 +1258,8 @@ void render_worker(mp_render* r, size_t wi) {
         r->next_tile.store(r->tiles.size(), std::memory_order_release);  // no new tiles for the other workers either
     };
     using Slot = mp_ctx::WorkerSlot;
-    Slot slot[2];
+    constexpr int kSlots = MP_RENDER_SLOTS;
+    Slot slot[kSlots];
     hipError_t e = hipSetDevice(ctx->device);
     if (e != hipSuccess) set_error(MP_ERR_HIP, std::string("render worker setup: ") + hipGetErrorString(e));
     for (Slot& s : slot)
@@ -1292,7 +1297,7 @@ void render_worker(mp_render* r, size_t wi) {
         size_t first = r->next_tile.fetch_add(batch, std::memory_order_acq_rel);
         if (first >= total) break;
         Slot& s = slot[cur];
-        retire(s);  // the batch issued two rounds ago
+        retire(s);  // the batch issued kSlots rounds ago
         if (my_status != MP_OK) break;
         s.first = first;
         s.n = std::min(batch, total - first);
@@ -1312,11 +1317,10 @@ void render_worker(mp_render* r, size_t wi) {
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_u8, s.d_u8, s.n * per_tile, hipMemcpyDeviceToHost, s.stream);
         if (e != hipSuccess) { set_error(MP_ERR_HIP, std::string("tile readback: ") + hipGetErrorString(e)); break; }
         s.busy = true;
-        cur ^= 1;
+        cur = (cur + 1) % kSlots;
     }
     // drain in issue order: slot[cur] holds the older batch
-    retire(slot[cur]);
-    retire(slot[cur ^ 1]);
+    for (int k = 0; k < kSlots; k++) retire(slot[(cur + k) % kSlots]);
     for (Slot& s : slot) {
         if (s.stream) (void)hipStreamSynchronize(s.stream);
         s.busy = false;
