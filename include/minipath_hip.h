@@ -254,6 +254,16 @@ int mp_scene_info_get(const mp_scene *scene, mp_scene_info *out);
  * Any pointer may be NULL. */
 int mp_scene_export(const mp_scene *scene, void *inner_nodes, void *packets, void *tri_shading, float *vertex_normals,
                     float *vertex_tex, uint32_t *tri_material);
+/* Diagnostics / tests (no reference counterpart): the traversal-format node array the kernels walk, rebuilt from
+ * the host tree by the code the upload uses; works on host-only scenes.  which = 0: the WIDE tree -- thin inner nodes of the
+ * reference tree absorbed into their parents where every child box is contained, in floating point, in its parent's box, which
+ * makes the hits of rays with finite inverse directions bit-identical (argument: minipath_amd/csrc/device_tree.cpp); which = 1:
+ * the literal reference tree (InnerNode n = node n), walked by rays with an infinite inverse direction component.
+ * nodes (nullable): count x 64 dwords = 8 child records {min.xyz, max.xyz (absolute f32), link, n}; link (u32 bits): inner =
+ * node index << 6, leaf = first packet << 6 | real triangles (1..56), null = 0xFFFFFFF8; n (u32 bits, record 0 only) = index of
+ * the last real child + 1.  absorbed = reference nodes that are no longer nodes of their own.  Any out pointer may be NULL. */
+int mp_scene_device_tree(const mp_scene *scene, int which, float *nodes, uint32_t *count, uint32_t *root_link,
+                         uint32_t *stack_bound, uint32_t *absorbed);
 
 /* ---- impl Object for TriangleBvh :: intersect, batched (ray_bvh_intersection.rs:26-96) -------------------- */
 /* d_o/d_d: SoA device arrays of n floats each (ox,oy,oz / dx,dy,dz).  Directions need not be unit: Ray::new

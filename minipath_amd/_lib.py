@@ -178,6 +178,7 @@ SIGNATURES = {
     "mp_scene_destroy": (None, [C.c_void_p]),
     "mp_scene_info_get": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
     "mp_scene_export": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mp_scene_device_tree": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "mp_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_void_p] * 6 + [C.c_uint64, C.POINTER(HitsSoA), C.c_void_p]),
     "mp_generate_rays": (
         C.c_int,

@@ -153,7 +153,9 @@ struct mp_scene {
     void* d_shade = nullptr;
     void* d_vidx = nullptr;
     void* d_vtex = nullptr;
-    void* d_nodes_aos = nullptr;
+    void* d_nodes_aos = nullptr;  // wide tree
+    void* d_nodes_lit = nullptr;  // literal tree
+    uint32_t wide_nodes = 0, absorbed_nodes = 0;
     void* d_tris_aos = nullptr;
     void* d_pkt_valid = nullptr;
     // material table of the path extension: shared by reference with the instanced scenes made from this scene (each keeps the
@@ -297,21 +299,6 @@ namespace {
 int upload_scene(mp_scene* s) {
     const HostBvh& h = s->host;
     const size_t ni = h.inner.size(), np = h.packets.size();
-    // host staging in SoA rows (the oracle's traversal-format layout); the device gets the AoS copies built from it below
-    std::vector<float> nodes(std::max<size_t>(ni, 1) * kNodeDwords, 0.0f);
-    for (size_t n = 0; n < ni; n++) {
-        const InnerNodeRef& nd = h.inner[n];
-        const Box3& e = h.inner_box[n];
-        float size[3] = {e.mx[0] - e.mn[0], e.mx[1] - e.mn[1], e.mx[2] - e.mn[2]};
-        float* o = &nodes[n * kNodeDwords];
-        for (int i = 0; i < 8; i++) {
-            for (int k = 0; k < 3; k++) {
-                o[k * 8 + i] = dequantise(nd.bmin[k][i], size[k], e.mn[k]);        // ray_bvh_intersection.rs:155
-                o[(3 + k) * 8 + i] = dequantise(nd.bmax[k][i], size[k], e.mn[k]);
-            }
-            std::memcpy(&o[48 + i], &nd.link[i], 4);
-        }
-    }
     std::vector<float> tris(np * kPacketDwords, 0.0f);
     std::vector<float> shade(np * 8 * 12, 0.0f);
     std::vector<uint32_t> vidx(np * 8 * 3, 0);
@@ -340,55 +327,20 @@ int upload_scene(mp_scene* s) {
             std::memcpy(&so[10], &mat, 4);
         }
     }
-    // the sign-specialised slab test of the packet walk relies on min <= max for every real child box
+    // node arrays (device_tree.cpp): the wide tree the walks normally use and the literal reference tree for rays with an
+    // infinite inverse direction component.  The sign-specialised slab test of the packet walk relies on min <= max for every
+    // real child box of either.
+    const std::vector<uint32_t> pkt_valid = packet_real_counts(h);
+    DeviceTree wide, lit;
     {
-        bool ordered = true;
-        for (size_t n = 0; n < ni && ordered; n++)
-            for (int i = 0; i < 8 && ordered; i++) {
-                uint32_t link;
-                std::memcpy(&link, &nodes[n * kNodeDwords + 48 + i], 4);
-                if (link == MP_LINK_NULL) continue;
-                for (int k = 0; k < 3; k++)
-                    if (!(nodes[n * kNodeDwords + k * 8 + i] <= nodes[n * kNodeDwords + (k + 3) * 8 + i])) ordered = false;
-            }
-        s->dev.boxes_ordered = ordered ? 1u : 0u;
+        std::string err;
+        int trc = build_device_tree(h, pkt_valid, true, wide, err);
+        if (!trc) trc = build_device_tree(h, pkt_valid, false, lit, err);
+        if (trc) return fail(trc, err);
     }
-    // AoS copies for the scalar-unit fetch of the ray-packet traversal (same values, different order)
-    // real (unpadded) triangles per packet: padding lanes are all-zero quantised triangles with default shading, at the tail of a
-    // leaf's last packet
-    std::vector<uint32_t> pkt_valid(np, 0);
-    for (size_t p = 0; p < np; p++)
-        for (int i = 0; i < 8; i++) {
-            bool pad = true;
-            for (int a = 0; a < 3 && pad; a++)
-                for (int k = 0; k < 3; k++)
-                    if (h.packets[p].v[a][k][i] != 0) { pad = false; break; }
-            const TriShadingRef& sh = h.shading[p * 8 + i];
-            pad = pad && sh.vi[0] == 0 && sh.vi[1] == 0 && sh.vi[2] == 0 && sh.flat == 0;
-            if (!pad) pkt_valid[p] = static_cast<uint32_t>(i + 1);
-        }
-    if (np >= (1u << 26) - 1u || ni >= (1u << 26)) return fail(MP_ERR_UNSUPPORTED, "scene too large for the device link format (2^26-2 packets)");
-    // device link (mp_internal.h): inner = index << 6 ; leaf = first packet << 6 | real triangles ; null unchanged
-    auto dlink = [&](uint32_t l) -> uint32_t {
-        if (l == MP_LINK_NULL) return l;
-        const uint32_t idx = l >> 3, cnt = l & 7u;
-        if (cnt == 0u) return idx << 6;
-        const uint32_t n_real = (cnt - 1u) * 8u + pkt_valid[idx + cnt - 1u];
-        return (idx << 6) | std::max<uint32_t>(n_real, 1u);  // a leaf of padding only (imported arrays) still tests one, never-hit, triangle
-    };
-    // child record = {min.xyz, max.xyz, dlink, n}: n (record 0 only) = index of the node's last real child + 1 (the packet walk's
-    // loop bound; the builder packs real children first, imported trees may have null links in between, which are skipped)
-    std::vector<float> nodes_aos(std::max<size_t>(ni, 1) * 64 + 16, 0.0f);  // + tail padding: the child loop fetches one record ahead
-    for (size_t n = 0; n < ni; n++) {
-        uint32_t nchild = 0;
-        for (int i = 0; i < 8; i++) {
-            for (int k = 0; k < 6; k++) nodes_aos[n * 64 + i * 8 + k] = nodes[n * kNodeDwords + k * 8 + i];
-            const uint32_t dl = dlink(h.inner[n].link[i]);
-            std::memcpy(&nodes_aos[n * 64 + i * 8 + 6], &dl, 4);
-            if (h.inner[n].link[i] != MP_LINK_NULL) nchild = static_cast<uint32_t>(i) + 1u;
-        }
-        std::memcpy(&nodes_aos[n * 64 + 7], &nchild, 4);
-    }
+    s->dev.boxes_ordered = (wide.boxes_ordered && lit.boxes_ordered) ? 1u : 0u;
+    s->wide_nodes = wide.count;
+    s->absorbed_nodes = wide.absorbed;
     std::vector<float> tris_aos(np * 8 * kTriDwords + 4 * kTriDwords, 0.0f);  // + tail padding: the triangle loop prefetches up to two ahead
     for (size_t p = 0; p < np; p++)
         for (int i = 0; i < 8; i++)
@@ -404,7 +356,8 @@ int upload_scene(mp_scene* s) {
     if ((rc = up(&s->d_shade, shade.data(), shade.size() * 4))) return rc;
     if ((rc = up(&s->d_vidx, vidx.data(), vidx.size() * 4))) return rc;
     if ((rc = up(&s->d_vtex, h.vtex.data(), h.vtex.size() * 4))) return rc;
-    if ((rc = up(&s->d_nodes_aos, nodes_aos.data(), nodes_aos.size() * 4))) return rc;
+    if ((rc = up(&s->d_nodes_aos, wide.nodes.data(), wide.nodes.size() * 4))) return rc;
+    if ((rc = up(&s->d_nodes_lit, lit.nodes.data(), lit.nodes.size() * 4))) return rc;
     if ((rc = up(&s->d_tris_aos, tris_aos.data(), tris_aos.size() * 4))) return rc;
     if ((rc = up(&s->d_pkt_valid, pkt_valid.data(), pkt_valid.size() * 4))) return rc;
     {
@@ -416,7 +369,8 @@ int upload_scene(mp_scene* s) {
     }
     s->dev.materials = static_cast<const float*>(s->mat_table->d);
     s->dev.sky = s->sky;
-    MP_HIP(hipMemcpy(s->d_nodes_aos, nodes_aos.data(), nodes_aos.size() * 4, hipMemcpyHostToDevice));
+    MP_HIP(hipMemcpy(s->d_nodes_aos, wide.nodes.data(), wide.nodes.size() * 4, hipMemcpyHostToDevice));
+    MP_HIP(hipMemcpy(s->d_nodes_lit, lit.nodes.data(), lit.nodes.size() * 4, hipMemcpyHostToDevice));
     if (!tris_aos.empty()) MP_HIP(hipMemcpy(s->d_tris_aos, tris_aos.data(), tris_aos.size() * 4, hipMemcpyHostToDevice));
     if (!pkt_valid.empty()) MP_HIP(hipMemcpy(s->d_pkt_valid, pkt_valid.data(), pkt_valid.size() * 4, hipMemcpyHostToDevice));
     if (!shade.empty()) MP_HIP(hipMemcpy(s->d_shade, shade.data(), shade.size() * 4, hipMemcpyHostToDevice));
@@ -426,38 +380,24 @@ int upload_scene(mp_scene* s) {
     s->dev.vidx = static_cast<const uint32_t*>(s->d_vidx);
     s->dev.vtex = static_cast<const float*>(s->d_vtex);
     s->dev.nodes_aos = static_cast<const float*>(s->d_nodes_aos);
+    s->dev.nodes_lit = static_cast<const float*>(s->d_nodes_lit);
     s->dev.tris_aos = static_cast<const float*>(s->d_tris_aos);
     s->dev.pkt_valid = static_cast<const uint32_t*>(s->d_pkt_valid);
-    s->dev.root = dlink(h.root);
-    s->dev.inner_count = static_cast<uint32_t>(ni);
+    s->dev.root = wide.root;
+    s->dev.root_lit = lit.root;
+    s->dev.inner_count = wide.count;
     s->dev.packet_count = static_cast<uint32_t>(np);
-    // Exact bound of the traversal stack: a node pushes at most its real (non-null) children in ascending order and pops
-    // them in descending order, so while the subtree of the child at position p is walked, p lower siblings wait below it.
-    // bound(node) = max(#children, max_p(p + bound(child_p))); far below the 7*depth+1 of eight-way nodes for the
-    // reference's narrow trees (teapot 22 vs 36, atrium 54 vs 197), which keeps the packet walk's stack in registers.
-    {
-        std::vector<uint32_t> bound(ni, 0);
-        for (size_t n = ni; n-- > 0;) {  // children have larger indices than their parent (pre-order numbering)
-            uint32_t p = 0, best = 0;
-            for (int i = 0; i < 8; i++) {
-                const uint32_t l = h.inner[n].link[i];
-                if (l == MP_LINK_NULL) continue;
-                const uint32_t sub = (l & 7u) == 0u ? bound[l >> 3] : 0u;
-                best = std::max(best, p + sub);
-                p++;
-            }
-            bound[n] = std::max(best, p);
-        }
-        s->dev.stack_cap = std::max<uint32_t>(1u, ((h.root & 7u) == 0u && h.root != MP_LINK_NULL) ? bound[h.root >> 3] : 1u);
-    }
+    // exact bound of the traversal stack (device_tree.cpp), over both trees: the walks share their stack storage
+    s->dev.stack_cap = std::max(wide.stack_bound, lit.stack_bound);
+    // union of the literal root's child boxes (the wide root's slots lie inside it: absorbed children are FP-nested)
     s->dev.has_pre = 0;
     if ((h.root & 7u) == 0u && h.root != MP_LINK_NULL) {  // root is an inner node
-        const float* o = &nodes[static_cast<size_t>(h.root >> 3) * kNodeDwords];
+        const float* o = &lit.nodes[static_cast<size_t>(h.root >> 3) * 64];
         bool any = false;
         for (int i = 0; i < 8; i++) {
             if (h.inner[h.root >> 3].link[i] == MP_LINK_NULL) continue;
             for (int k = 0; k < 3; k++) {
-                float mn = o[k * 8 + i], mx = o[(3 + k) * 8 + i];
+                float mn = o[i * 8 + k], mx = o[i * 8 + 3 + k];
                 s->dev.pre_min[k] = any ? std::fmin(s->dev.pre_min[k], mn) : mn;
                 s->dev.pre_max[k] = any ? std::fmax(s->dev.pre_max[k], mx) : mx;
             }
@@ -814,8 +754,8 @@ int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* rotatio
             const DevScene& d = objects[i]->dev;
             DevObject& o = desc[i];
             std::memset(&o, 0, sizeof(o));
-            o.shade = d.shade; o.nodes_aos = d.nodes_aos; o.tris_aos = d.tris_aos; o.vidx = d.vidx; o.vtex = d.vtex;
-            o.root = d.root; o.has_pre = d.has_pre;
+            o.shade = d.shade; o.nodes_aos = d.nodes_aos; o.nodes_lit = d.nodes_lit; o.tris_aos = d.tris_aos; o.vidx = d.vidx; o.vtex = d.vtex;
+            o.root = d.root; o.root_lit = d.root_lit; o.has_pre = d.has_pre;
             o.kind = d.kind; o.sphere_radius = d.sphere_radius;
             for (int k = 0; k < 3; k++) {
                 o.pre_min[k] = d.pre_min[k]; o.pre_max[k] = d.pre_max[k]; o.t[k] = translations[3 * i + k];
@@ -910,7 +850,7 @@ void mp_scene_destroy(mp_scene* s) {
     }
     if (s->ctx) {
         DeviceGuard g(s->ctx->device);
-        for (void* p : {s->d_shade, s->d_vidx, s->d_vtex, s->d_nodes_aos, s->d_tris_aos, s->d_pkt_valid})
+        for (void* p : {s->d_shade, s->d_vidx, s->d_vtex, s->d_nodes_aos, s->d_nodes_lit, s->d_tris_aos, s->d_pkt_valid})
             if (p) (void)hipFree(p);
     }
     delete s;
@@ -958,6 +898,26 @@ int mp_scene_export(const mp_scene* s, void* inner_nodes, void* packets, void* t
     if (vertex_normals && !h.vnormal.empty()) std::memcpy(vertex_normals, h.vnormal.data(), h.vnormal.size() * 4);
     if (vertex_tex && !h.vtex.empty()) std::memcpy(vertex_tex, h.vtex.data(), h.vtex.size() * 4);
     if (tri_material && !h.material.empty()) std::memcpy(tri_material, h.material.data(), h.material.size() * 4);
+    return MP_OK;
+    });
+}
+
+int mp_scene_device_tree(const mp_scene* s, int which, float* nodes, uint32_t* count, uint32_t* root_dlink, uint32_t* stack_bound,
+                         uint32_t* absorbed) {
+    return guarded([&]() -> int {
+    if (!s) return fail(MP_ERR_INVALID, "scene is NULL");
+    if (which != 0 && which != 1) return fail(MP_ERR_INVALID, "which must be 0 (wide tree) or 1 (literal tree)");
+    if (s->dev.kind != 0u || (s->inst_of && !s->one_object)) return fail(MP_ERR_UNSUPPORTED, "only a TriangleBvh scene has a node tree of its own");
+    const HostBvh& h = s->inst_of ? s->inst_of->host : s->host;
+    DeviceTree t;
+    std::string err;
+    const int rc = build_device_tree(h, packet_real_counts(h), which == 0, t, err);  // rebuilt from the host tree: same code, same floats as the upload
+    if (rc) return fail(rc, err);
+    if (nodes && t.count) std::memcpy(nodes, t.nodes.data(), static_cast<size_t>(t.count) * 64 * sizeof(float));
+    if (count) *count = t.count;
+    if (root_dlink) *root_dlink = t.root;
+    if (stack_bound) *stack_bound = t.stack_bound;
+    if (absorbed) *absorbed = t.absorbed;
     return MP_OK;
     });
 }

@@ -188,7 +188,10 @@ __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __res
     uint32_t pk = 0, pk_end = 0, seq = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0, ix = 0, iy = 0, iz = 0;
     // Lane li fetches child li / triangle li as whole 16-byte words from the AoS copies (two loads per node, three per packet)
-    const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(sc.nodes_aos);
+    // PATCH_NAN = some queued ray has an infinite inverse direction component: literal reference tree; otherwise the wide tree
+    // (thin nodes absorbed into their parents: same hits for finite inverses, device_tree.cpp)
+    const float4* __restrict__ nodes4 = reinterpret_cast<const float4*>(PATCH_NAN ? sc.nodes_lit : sc.nodes_aos);
+    const uint32_t root = PATCH_NAN ? sc.root_lit : sc.root;
     const float* __restrict__ tris = sc.tris_aos;
     float best_t = FLT_MAX;                 // best.t, group-uniform (ray_bvh_intersection.rs:34-37)
     float tl = FLT_MAX, ul = 0, vl = 0;     // this lane's earliest closest candidate
@@ -239,7 +242,7 @@ __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __res
                 best_t = FLT_MAX; tl = FLT_MAX; ul = 0; vl = 0; pkl = kNoPrim; seql = 0; seq = 0;
                 pk = pk_end = 0;
                 sp = 1;
-                if (li == 0) stack[0] = make_uint2(sc.root, as_u(-INFINITY));  // :28-32
+                if (li == 0) stack[0] = make_uint2(root, as_u(-INFINITY));  // :28-32
             }
             if (__ballot(slot >= 0) == 0) break;
         }
@@ -307,13 +310,16 @@ __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __res
     wave_lds_sync();
 }
 
-// A queue without a ray that has a zero direction component cannot produce 0 * inf in the slab test: it runs the variant
-// without the NaN patches (six VALU per node step less).  Wave-uniform choice per call.
+// A queue without a ray that has an infinite inverse direction component (a zero -- or, denormals being kept, a tiny --
+// direction component: geometry/mod.rs:49-53) cannot produce 0 * inf in the slab test: it runs the variant without the NaN
+// patches (six VALU per node step less) on the wide tree.  Wave-uniform choice per call.
 template <bool BFE = false>
 __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict__ q, uint2* __restrict__ stack_base, int nrays) {
     const int lane = static_cast<int>(threadIdx.x) & 63;
-    const bool zero = lane < nrays && (q[3 * 64 + lane] == 0.0f || q[4 * 64 + lane] == 0.0f || q[5 * 64 + lane] == 0.0f);
-    if (__ballot(zero) != 0) trace_wave_impl<true, BFE>(sc, q, stack_base, nrays);
+    const float qx = q[3 * 64 + lane], qy = q[4 * 64 + lane], qz = q[5 * 64 + lane];
+    const float ix = (qx == 0.0f) ? INFINITY : 1.0f / qx, iy = (qy == 0.0f) ? INFINITY : 1.0f / qy, iz = (qz == 0.0f) ? INFINITY : 1.0f / qz;
+    const bool inf = lane < nrays && (fabsf(ix) == INFINITY || fabsf(iy) == INFINITY || fabsf(iz) == INFINITY);
+    if (__ballot(inf) != 0) trace_wave_impl<true, BFE>(sc, q, stack_base, nrays);
     else trace_wave_impl<false, BFE>(sc, q, stack_base, nrays);
 }
 
@@ -384,8 +390,8 @@ __device__ __forceinline__ bool sphere_intersect(const DevScene& sc, const Ray& 
 __device__ __forceinline__ void object_scene(const DevScene& sc, uint32_t k, DevScene& sk) {
     sk = sc;
     const DevObject& o = sc.objects[k];
-    sk.shade = o.shade; sk.nodes_aos = o.nodes_aos; sk.tris_aos = o.tris_aos; sk.vidx = o.vidx; sk.vtex = o.vtex;
-    sk.root = o.root; sk.has_pre = o.has_pre;
+    sk.shade = o.shade; sk.nodes_aos = o.nodes_aos; sk.nodes_lit = o.nodes_lit; sk.tris_aos = o.tris_aos; sk.vidx = o.vidx; sk.vtex = o.vtex;
+    sk.root = o.root; sk.root_lit = o.root_lit; sk.has_pre = o.has_pre;
     sk.kind = o.kind; sk.sphere_radius = o.sphere_radius;
     for (int i = 0; i < 3; i++) { sk.pre_min[i] = o.pre_min[i]; sk.pre_max[i] = o.pre_max[i]; sk.sphere_center[i] = o.sphere_center[i]; }
 }
@@ -775,12 +781,14 @@ __device__ __forceinline__ uint32_t uniform_u(float f) { return __builtin_amdgcn
 template <int MODE, int OCT, class Stack>
 __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
     constexpr bool PATCH_NAN = MODE == 2;
-    kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
+    // MODE 2 walks the literal reference tree, MODE 1 the wide tree (thin nodes absorbed into their parents: bit-identical hits
+    // for rays with finite inverse directions, device_tree.cpp)
+    kfp nodes = (kfp)(uintptr_t)(PATCH_NAN ? sc.nodes_lit : sc.nodes_aos);
     kfp tris = (kfp)(uintptr_t)sc.tris_aos;
     float best_t = FLT_MAX, bu = 0.0f, bv = 0.0f;  // best (:34-37)
     uint32_t bprim = kNoPrim;
     // entry 0 = root (:28-32), t1 = -inf: never culled
-    st.push(0, sc.root, kSrcRoot, __ballot(active));
+    st.push(0, PATCH_NAN ? sc.root_lit : sc.root, kSrcRoot, __ballot(active));
     st.sync(1);
     int sp = 1;
     int stale_top = 0;  // entries [0, stale_top) were pushed before some ray's best.t last changed
@@ -949,12 +957,12 @@ template <int MODE, int OCT>
 __device__ __forceinline__ void trace_packet2_impl(const DevScene& sc, const Ray& ra, const Ray& rb, bool active_a, bool active_b,
                                                    PacketHit& hit_a, PacketHit& hit_b) {
     constexpr bool PATCH_NAN = MODE == 2;
-    kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
+    kfp nodes = (kfp)(uintptr_t)(PATCH_NAN ? sc.nodes_lit : sc.nodes_aos);  // literal / wide tree, as in trace_packet_impl
     kfp tris = (kfp)(uintptr_t)sc.tris_aos;
     RegStack2 st;
     float best_a = FLT_MAX, ua = 0.0f, va = 0.0f, best_b = FLT_MAX, ub = 0.0f, vb = 0.0f;  // best (:34-37), per ray
     uint32_t prim_a = kNoPrim, prim_b = kNoPrim;
-    st.push(0, sc.root, kSrcRoot, __ballot(active_a), __ballot(active_b));  // entry 0 = root (:28-32), never culled
+    st.push(0, PATCH_NAN ? sc.root_lit : sc.root, kSrcRoot, __ballot(active_a), __ballot(active_b));  // entry 0 = root (:28-32), never culled
     int sp = 1;
     int stale_top = 0;  // entries [0, stale_top) were pushed before some ray's best.t last changed
     while (sp > 0) {

@@ -60,9 +60,25 @@ int load_obj(const char* path, std::vector<float>& pos, std::vector<float>& nrm,
 // chain, depth and triangle count.
 int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err);
 
+// Traversal-format node array (device_tree.cpp): `count` nodes x 8 child records x 8 dwords (+ tail padding), the dlink of the
+// root, the exact traversal-stack bound and whether every real child box has min <= max.  wide = thin nodes absorbed into
+// their parents (the tree the walks use for rays with finite inverse directions); otherwise the literal reference tree.
+struct DeviceTree {
+    std::vector<float> nodes;
+    uint32_t count = 0;
+    uint32_t root = MP_LINK_NULL;
+    uint32_t stack_bound = 1;
+    uint32_t absorbed = 0;       // reference nodes that no longer exist as nodes of their own (wide tree)
+    bool boxes_ordered = true;
+};
+std::vector<uint32_t> packet_real_counts(const HostBvh& h);  // real (unpadded) triangles of each packet
+int build_device_tree(const HostBvh& h, const std::vector<uint32_t>& pkt_valid, bool wide, DeviceTree& out, std::string& err);
+
 // ---- device scene ("traversal format") -------------------------------------------------------
-// nodes_aos : inner_count x 8 children x 8 dwords {minx,miny,minz,maxx,maxy,maxz,dlink,n}: absolute decompressed child boxes;
-//             n (record 0 only) = index of the node's last real child + 1.
+// nodes_aos : node_count x 8 children x 8 dwords {minx,miny,minz,maxx,maxy,maxz,dlink,n}: absolute decompressed child boxes;
+//             n (record 0 only) = index of the node's last real child + 1.  This is the WIDE tree (device_tree.cpp: thin nodes
+//             absorbed into their parents, bit-identical hits for rays with finite inverse directions); nodes_lit / root_lit are
+//             the literal reference tree in the same format, walked by rays with an infinite inverse direction component.
 // dlink     : device-private link (the reference's CompressedNodeLink idx<<3|count, mod.rs:57-114, re-encoded so that a leaf needs
 //             no side lookup): inner = node index << 6 ; leaf = first packet << 6 | real (unpadded) triangles of the leaf (1..56) ;
 //             null = MP_LINK_NULL unchanged (checked before decoding; scenes are limited to 2^26-2 packets).
@@ -74,13 +90,14 @@ int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err);
 // shade     : packet_count*8 x 3 float4 : n0.xyz n1.xyz n2.xyz flat(u32 bits) material(u32 bits) pad.  48 B per triangle slot.
 // vidx/vtex : for the full HitRecord (texture_coords).
 // One member {object, translation} of a build-defined object group (mp_scene_group / mp_scene_instances): the member's own
-// traversal arrays (borrowed from its scene) or its sphere, and the rigid transform that places it.  128 bytes.
+// traversal arrays (borrowed from its scene) or its sphere, and the rigid transform that places it.  136 bytes.
 struct DevObject {
     const float* shade;
     const float* nodes_aos;
     const float* tris_aos;
     const uint32_t* vidx;
     const float* vtex;
+    const float* nodes_lit;
     uint32_t root;
     uint32_t has_pre;
     float pre_min[3], pre_max[3];
@@ -90,16 +107,17 @@ struct DevObject {
     float sphere_radius;
     float q[4];                 // rotation (unit quaternion i, j, k, w): world = q * local + t
     uint32_t rotated;           // 0 = translation only (q is not applied: the ray keeps its exact direction)
-    uint32_t pad;
+    uint32_t root_lit;
 };
-static_assert(sizeof(DevObject) == 128, "DevObject layout");
+static_assert(sizeof(DevObject) == 136, "DevObject layout");
 
 struct DevScene {
     uint32_t kind = 0;               // 0 = TriangleBvh, 1 = Sphere (scene/primitives.rs:10-13)
     float sphere_center[3] = {0, 0, 0};
     float sphere_radius = 0;
     const float* shade = nullptr;
-    const float* nodes_aos = nullptr;
+    const float* nodes_aos = nullptr;  // wide tree
+    const float* nodes_lit = nullptr;  // literal tree
     const float* tris_aos = nullptr;
     const uint32_t* pkt_valid = nullptr;
     const uint32_t* vidx = nullptr;  // packets*8*3
@@ -108,8 +126,9 @@ struct DevScene {
     float sky = 1.0f;                  // ... and the sky radiance
     uint32_t inst_count = 0;           // build-defined object group: number of members; 0 = plain BVH
     const struct DevObject* objects = nullptr;  // ... and their descriptors (device)
-    uint32_t root = MP_LINK_NULL;    // dlink of the root
-    uint32_t inner_count = 0;
+    uint32_t root = MP_LINK_NULL;    // dlink of the root (wide tree)
+    uint32_t root_lit = MP_LINK_NULL;  // ... in the literal tree
+    uint32_t inner_count = 0;        // nodes of the wide tree
     uint32_t packet_count = 0;
     uint32_t stack_cap = 1;          // exact traversal-stack bound (upload_scene)
     uint32_t packet_stack_regs = 64; // entries of the packet walk's stack held in registers (test knob, <= 64)

@@ -115,6 +115,17 @@ class TriangleBvh:
         i = self.info()
         return np.array(list(i.bbox_min), np.float32), np.array(list(i.bbox_max), np.float32)
 
+    def device_tree(self, literal: bool = False):
+        """The traversal-format node array the kernels walk (mp_scene_device_tree; diagnostics / tests): returns
+        (nodes (n, 8, 8) u32 view of {min.xyz, max.xyz, link, n} records, root link, stack bound, absorbed reference nodes).
+        literal=False: the wide tree (thin nodes absorbed into their parents); True: the literal reference tree."""
+        n, root, bound, absorbed = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        which = 1 if literal else 0
+        _lib.check(_lib.lib().mp_scene_device_tree(self.handle, which, None, C.byref(n), C.byref(root), C.byref(bound), C.byref(absorbed)))
+        nodes = np.zeros((n.value, 8, 8), np.uint32)
+        _lib.check(_lib.lib().mp_scene_device_tree(self.handle, which, nodes.ctypes.data, None, None, None, None))
+        return nodes, root.value, bound.value, absorbed.value
+
     def export(self, with_material: bool = False):
         """Reference-layout arrays: inner nodes (n,128) u8, packets (n,144) u8, tri shading (n*8,4) u32,
         vertex normals / tex (nv,3) f32 (+ material id per triangle slot (n*8,) u32 with with_material=True)."""
