@@ -158,6 +158,9 @@ typedef struct {
 /* BUILD-DEFINED path extension (MP_FLAG_PATHS): grey diffuse material, indexed by TriangleShadingData.material.  The
  * reference carries `material: usize` in every HitRecord (geometry/mod.rs:78) but only ever writes 0 and never reads it. */
 typedef struct { float albedo, emission; } mp_material;
+/* Material ids (mp_scene_from_triangles_mat, mp_bvh_desc.tri_material, OBJ `usemtl`) must be below this: a scene's material
+ * table has max id + 1 entries, so an unbounded id would size a table of gigabytes (MP_ERR_INVALID otherwise). */
+#define MP_MAX_MATERIALS 65536u
 
 /* geometry/mod.rs:71-80 HitRecord, batched SoA on the device (any pointer may be NULL to skip that output) */
 typedef struct {
@@ -238,7 +241,8 @@ int mp_scene_sphere(mp_ctx *ctx, const float center[3], float radius, mp_scene *
  * The group has ONE material table indexed by the members' material ids (initially the first member's, padded with the default
  * material; mp_scene_set_materials replaces it) and the first member's sky radiance.  get_bounding_box = union of the members'
  * boxes in the world frame (rotated member: the box of its box's rotated corners); mp_scene_info counts are sums over the
- * members.  The group SHARES its members' device arrays: they must outlive it.  Rendered by the 8-lane-group traversal (every
+ * members.  The group SHARES its members' device arrays and holds a reference on each member: mp_scene_destroy on a member only
+ * drops the caller's handle, the arrays are freed when the last group using them is destroyed too.  Rendered by the 8-lane-group traversal (every
  * kernel but the staged MP_FLAG_WAVEFRONT pipeline); defined operation by operation in oracle/minipath_oracle.c
  * (bvh_intersect_impl). */
 int mp_scene_group(mp_ctx *ctx, const mp_scene *const *objects, const float *rotations, const float *translations, uint32_t n,

@@ -4,7 +4,7 @@ Host-side mirror of the reference's public API (src/lib.rs:8-10): ``render``, ``
 ``RenderSettings``, ``Camera``, ``Scene`` and ``TriangleBvh``, over the C ABI of ``include/minipath_hip.h``.
 All compute happens in ``csrc/libminipath_hip.so`` (hand-written HIP kernels); there is no CPU path here.
 """
-from ._lib import MinipathError, MP_NO_PRIM, MP_LINK_NULL, SO_PATH  # noqa: F401
+from ._lib import MinipathError, MP_NO_PRIM, MP_LINK_NULL, MAX_MATERIALS, SO_PATH  # noqa: F401
 from .camera import Camera, CameraSampler  # noqa: F401
 from .screen_block import ScreenBlock, tile_ordering  # noqa: F401
 from .scene import Context, Instances, ObjectGroup, Scene, Sphere, TriangleBvh  # noqa: F401

@@ -23,6 +23,9 @@ MP_FLAG_WAVEFRONT = 16
 MP_FLAG_CHUNKED_SUM = 32
 
 
+MAX_MATERIALS = 65536  # MP_MAX_MATERIALS (include/minipath_hip.h)
+
+
 class MinipathError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"minipath_hip error {code}: {message}")

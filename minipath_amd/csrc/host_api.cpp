@@ -182,6 +182,9 @@ struct mp_scene {
     float sky = 1.0f;
     uint32_t material_count = 1;  // max TriangleShadingData.material + 1
     uint64_t device_bytes = 0;
+    // An object group borrows its members' device arrays and host trees: every group holds one reference on each of its members,
+    // so mp_scene_destroy on a member only drops the caller's reference and the arrays live until the last group has gone too.
+    std::atomic<int> refs{1};
 };
 
 #ifndef MP_RENDER_SLOTS
@@ -298,7 +301,7 @@ namespace {
 
 int upload_scene(mp_scene* s) {
     const HostBvh& h = s->host;
-    const size_t ni = h.inner.size(), np = h.packets.size();
+    const size_t np = h.packets.size();
     std::vector<float> tris(np * kPacketDwords, 0.0f);
     std::vector<float> shade(np * 8 * 12, 0.0f);
     std::vector<uint32_t> vidx(np * 8 * 3, 0);
@@ -412,6 +415,7 @@ int finish_scene(mp_ctx* ctx, std::unique_ptr<mp_scene> s, mp_scene** out) {
     s->ctx = ctx;
     uint32_t mc = 0;
     for (uint32_t m : s->host.material) mc = std::max(mc, m);
+    if (mc >= MP_MAX_MATERIALS) return fail(MP_ERR_INVALID, "material id out of range (MP_MAX_MATERIALS)");  // build_bvh / bvh_from_arrays reject these already
     s->material_count = mc + 1;
     s->materials.assign(s->material_count, mp_material{0.75f, 0.0f});
     if (!ctx) {  // host-only scene: build + export work, nothing is uploaded and nothing can be rendered
@@ -772,14 +776,17 @@ int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* rotatio
         s->dev.objects = static_cast<const DevObject*>(s->d_inst);
         s->device_bytes = desc.size() * sizeof(DevObject);
         {  // the group's own copy of the table: a later mp_scene_set_materials on a member does not reach the group
-            auto tb = std::make_shared<mp_scene::DevTable>();
+            auto tb = std::make_shared<mp_scene::DevTable>();  // (its destructor frees the table on the error paths below)
             tb->device = ctx->device;
-            MP_HIP(hipMalloc(&tb->d, std::max<size_t>(16, s->materials.size() * sizeof(mp_material))));
-            MP_HIP(hipMemcpy(tb->d, s->materials.data(), s->materials.size() * sizeof(mp_material), hipMemcpyHostToDevice));
+            e = hipMalloc(&tb->d, std::max<size_t>(16, s->materials.size() * sizeof(mp_material)));
+            if (e == hipSuccess) e = hipMemcpy(tb->d, s->materials.data(), s->materials.size() * sizeof(mp_material), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(s->d_inst); return hip_fail(e, "material table of the object group"); }
             s->mat_table = std::move(tb);
             s->dev.materials = static_cast<const float*>(s->mat_table->d);
         }
     }
+    // the group is complete: one reference per member it borrows from (instances of one object: one in all)
+    for (size_t i = 0; i < (one_object ? 1 : static_cast<size_t>(n)); i++) const_cast<mp_scene*>(objects[i])->refs.fetch_add(1, std::memory_order_relaxed);
     *out = s.release();
     return MP_OK;
 }
@@ -838,13 +845,16 @@ int mp_scene_sphere(mp_ctx* ctx, const float center[3], float radius, mp_scene**
     });
 }
 
-void mp_scene_destroy(mp_scene* s) {
-    if (!s) return;
-    if (s->inst_of) {  // an instanced scene owns only its translation array (and, if re-set, its material table)
+namespace {
+void scene_release(mp_scene* s) {
+    if (!s || s->refs.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+    if (s->inst_of) {  // an object group owns its descriptor array (and, if re-set, its material table) and a reference per member
         if (s->ctx) {
             DeviceGuard g(s->ctx->device);
             if (s->d_inst) (void)hipFree(s->d_inst);
         }
+        const size_t held = s->one_object ? 1 : s->members.size();
+        for (size_t i = 0; i < held; i++) scene_release(const_cast<mp_scene*>(s->members[i]));
         delete s;
         return;
     }
@@ -855,6 +865,9 @@ void mp_scene_destroy(mp_scene* s) {
     }
     delete s;
 }
+}  // namespace
+
+void mp_scene_destroy(mp_scene* s) { scene_release(s); }
 
 int mp_scene_info_get(const mp_scene* s, mp_scene_info* out) {
     return guarded([&]() -> int {

@@ -455,6 +455,9 @@ int build_bvh(const float* pos, const float* nrm, const float* tex, uint32_t nv,
     if (!pos || !tri) { err = "null positions/indices"; return MP_ERR_INVALID; }
     for (size_t i = 0; i < static_cast<size_t>(nt) * 3; i++)
         if (tri[i] >= nv) { err = "vertex index out of range"; return MP_ERR_INVALID; }
+    if (tri_mat)
+        for (size_t i = 0; i < nt; i++)
+            if (tri_mat[i] >= MP_MAX_MATERIALS) { err = "material id out of range (MP_MAX_MATERIALS)"; return MP_ERR_INVALID; }
     out.vertex_count = nv;
     out.vnormal.assign(static_cast<size_t>(nv) * 3, 0.0f);
     out.vtex.assign(static_cast<size_t>(nv) * 3, 0.0f);
@@ -474,6 +477,7 @@ int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err) {
     out = HostBvh{};
     if ((d.inner_count && !d.inner_nodes) || (d.packet_count && (!d.packets || !d.tri_shading))) { err = "NULL array"; return MP_ERR_INVALID; }
     if (d.vertex_count && !d.vertex_normals) { err = "NULL vertex normals"; return MP_ERR_INVALID; }
+    if (d.packet_count && d.vertex_count == 0) { err = "triangle packets but no vertices"; return MP_ERR_INVALID; }
     if (d.inner_count > kMaxIndex || d.packet_count > kMaxIndex) { err = "more nodes/packets than a CompressedNodeLink can address (mod.rs:66)"; return MP_ERR_INVALID; }
     const size_t ni = d.inner_count, np = d.packet_count;
     out.inner.resize(ni);
@@ -494,7 +498,9 @@ int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err) {
     out.material_names.assign(1, std::string());
     for (const TriShadingRef& sh : out.shading)
         for (int v = 0; v < 3; v++)
-            if (sh.vi[v] >= std::max<uint32_t>(d.vertex_count, 1u)) { err = "vertex index out of range in tri_shading"; return MP_ERR_INVALID; }
+            if (sh.vi[v] >= d.vertex_count) { err = "vertex index out of range in tri_shading"; return MP_ERR_INVALID; }
+    for (uint32_t m : out.material)
+        if (m >= MP_MAX_MATERIALS) { err = "material id out of range (MP_MAX_MATERIALS)"; return MP_ERR_INVALID; }
     out.inner_box.assign(ni, Box3{});
     out.packet_box.assign(np, Box3{});
     std::vector<uint8_t> inner_seen(ni, 0), packet_seen(np, 0);

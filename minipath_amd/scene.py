@@ -86,6 +86,13 @@ class TriangleBvh:
         vn = np.ascontiguousarray(vertex_normals, np.float32).reshape(-1, 3)
         vt = None if vertex_tex is None else np.ascontiguousarray(vertex_tex, np.float32).reshape(-1, 3)
         mat = None if tri_material is None else np.ascontiguousarray(tri_material, np.uint32).reshape(-1)
+        # the C side copies packet_count * 8 rows of each per-triangle array: a short array would be read out of bounds
+        if shading.shape[0] != packets.shape[0] * 8:
+            raise ValueError(f"shading must have packet_count * 8 = {packets.shape[0] * 8} rows, got {shading.shape[0]}")
+        if mat is not None and mat.shape[0] != packets.shape[0] * 8:
+            raise ValueError(f"tri_material must have packet_count * 8 = {packets.shape[0] * 8} entries, got {mat.shape[0]}")
+        if vt is not None and vt.shape[0] != vn.shape[0]:
+            raise ValueError("vertex_tex must have one row per vertex normal")
         d = _lib.BvhDesc(
             inner.ctypes.data, packets.ctypes.data, shading.ctypes.data, mat.ctypes.data if mat is not None else None,
             vn.ctypes.data, vt.ctypes.data if vt is not None else None, inner.shape[0], packets.shape[0], vn.shape[0],

@@ -138,6 +138,21 @@ def test_trace_non_finite_and_extreme_rays(teapot, oracle, teapot_oracle_bvh):
     sl = block(128); o[sl, 0] = bmin[0]                  # origin exactly on the box's faces
     sl = block(128); o[sl, 1] = bmax[1]; d[sl, 1] = 0.0  # ... sliding along one
     sl = block(64); o[sl] = np.float32(1e-42)            # denormal origin
+    # a direction component small enough that 1/d overflows to +-inf (denormals are kept) with the origin exactly on a
+    # child-box plane of the same axis gives 0 * inf = NaN in the slab test, which aabb.rs:262-267 patches to -inf / +inf: these
+    # rays must take the walk with the NaN patches (and the literal tree), chosen from the inverse, not from `d == 0`
+    lit = teapot.object.device_tree(literal=True)[0]
+    boxes = lit[:, :, :6].view(np.float32).reshape(-1, 6)[lit[:, :, 6].reshape(-1) != 0xFFFFFFF8]
+    sl = block(256)
+    for j, i in enumerate(range(sl.start, sl.stop)):
+        b = boxes[rng.integers(0, boxes.shape[0])]
+        ax = j % 3
+        tgt = b[:3] + (b[3:] - b[:3]) * rng.random(3, dtype=np.float32)
+        dd = rng.standard_normal(3).astype(np.float32)
+        dd[ax] = np.float32(1e-40) * (1 if (j // 3) % 2 else -1)   # |1/d| = inf after Ray::new's normalisation
+        oo = (tgt - dd * np.float32(2.0)).astype(np.float32)
+        oo[ax] = b[ax] if (j // 6) % 2 else b[3 + ax]              # exactly on the child box's min / max plane
+        o[i], d[i] = oo, dd
     assert k <= n
     got, exp = _trace_both(teapot, teapot_oracle_bvh, o, d, full=True)
     _assert_hits_equal(got, exp)

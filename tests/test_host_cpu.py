@@ -317,6 +317,36 @@ def test_from_arrays_rejects_malformed_trees():
     sh = shading.copy(); sh[3, 1] = i.vertex_count                        # vertex index out of range
     with pytest.raises(mp.MinipathError):
         mp.TriangleBvh.from_arrays(**args(shading=sh))
+    # packets but no vertices (every index is then out of range); short per-triangle arrays; unbounded material ids
+    with pytest.raises(mp.MinipathError):
+        mp.TriangleBvh.from_arrays(**args(vertex_normals=np.zeros((0, 3), np.float32), vertex_tex=None))
+    with pytest.raises(ValueError):
+        mp.TriangleBvh.from_arrays(**args(shading=shading[:-8]))
+    with pytest.raises(ValueError):
+        mp.TriangleBvh.from_arrays(**args(tri_material=mat[:-1]))
+    m = mat.copy(); m[5] = 0xFFFFFFFF
+    with pytest.raises(mp.MinipathError):
+        mp.TriangleBvh.from_arrays(**args(tri_material=m))
+    m = mat.copy(); m[5] = mp.MAX_MATERIALS
+    with pytest.raises(mp.MinipathError):
+        mp.TriangleBvh.from_arrays(**args(tri_material=m))
+    m = mat.copy(); m[5] = mp.MAX_MATERIALS - 1                           # the largest id allowed
+    assert mp.TriangleBvh.from_arrays(**args(tri_material=m)).info().material_count == mp.MAX_MATERIALS
+
+
+def test_material_ids_are_bounded():
+    """tri_material = 0xFFFFFFFF used to wrap material_count to 0 (a 16-byte device table read at index
+    2^32-1 by the path kernels); mid-range ids sized multi-GB tables.  Ids at or above MP_MAX_MATERIALS are now MP_ERR_INVALID."""
+    pos, nrm, tex, tri = meshes.make("soup_300")
+    for bad in (0xFFFFFFFF, 1 << 28, mp.MAX_MATERIALS):
+        m = np.zeros(tri.shape[0], np.uint32); m[7] = bad
+        with pytest.raises(mp.MinipathError):
+            mp.TriangleBvh.build(pos, nrm, tex, tri, tri_material=m)
+    m = np.zeros(tri.shape[0], np.uint32); m[7] = mp.MAX_MATERIALS - 1
+    b = mp.TriangleBvh.build(pos, nrm, tex, tri, tri_material=m)
+    assert b.info().material_count == mp.MAX_MATERIALS
+    with pytest.raises(mp.MinipathError):
+        b.set_materials([(0.5, 0.0)])   # shorter than material_count
 
 
 def test_obj_usemtl_material_ids(tmp_path, oracle):
@@ -417,6 +447,15 @@ def test_object_group_host_side():
     ii = inst.info()
     assert ii.triangle_count == ib.triangle_count and ii.inner_count == ib.inner_count and ii.material_count == 4
     assert len(inst.export()) >= 5
+    # a group holds a reference on each member, so destroying the members first leaves the group usable (its info
+    # and export read the members' host trees) -- run under the ASAN build by tools/asan_cpu_tests.sh
+    exported = [x.copy() for x in inst.export()]
+    b.close(); a.close()
+    assert inst.info().triangle_count == ib.triangle_count and g.info().triangle_count == ig.triangle_count
+    for x, y in zip(inst.export(), exported):
+        assert np.array_equal(x, y)
+    assert inst.device_tree()[0].shape[0] + inst.device_tree()[3] == ib.inner_count
+    inst.close(); g.close(); gs.close()
 
 
 def test_oracle_group_is_the_members_traced_one_by_one():
