@@ -29,10 +29,11 @@ tiles first; mp_launch_extras / FrameRenderer.rebalance).  The work and the imag
 roofline: SURVEY 8(d) prices the path as a wavefront pipeline with 136 algorithmic HBM bytes per depth-1 ray (320 per bounce
 segment); `achieved` / `frac` follow that definition and are MODELLED bytes over measured kernel time ("modelled": true).
 The fused kernels keep ray state in registers, so their real HBM traffic is far smaller: `traffic` (bytes per launch) and
-`hbm_measured_gbs` come from rocprofv3 PMC counters of the same workload (profiles/r02_counters.json; FETCH_SIZE x 2 +
+`hbm_measured_gbs` come from rocprofv3 PMC counters of the same workload (profiles/r03_counters.json; FETCH_SIZE x 2 +
 WRITE_SIZE, the guide's gfx950 correction), and the actual limiter is reported as `valu_issue_frac` = SQ_INSTS_VALU x 2 cycles
 / (SIMDs x 2.4 GHz x kernel time) and `salu_issue_frac` = SQ_INSTS_SALU / (CUs x 2.4 GHz x kernel time), both with the live
-kernel time of this run.
+kernel time of this run.  The counters file records the SHA-256 of the device sources it was collected from; when the tree's
+differ, the line carries "counters_stale": true and none of the counter-derived figures.
 """
 import argparse
 import json
@@ -50,7 +51,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 SHADER_CLOCK_HZ = 2.4e9  # MI355X_MICROARCH.md: peak engine clock
 VALU_CYCLES = 2  # wave64 VALU instruction on a SIMD-32: 2 issue cycles (MI355X_MICROARCH.md "Per-instruction cycle constants")
 TEAPOT = os.path.join(ROOT, "tests", "golden", "teapot.obj")
-COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")
+COUNTERS = os.path.join(ROOT, "profiles", "r03_counters.json")
+# sources that decide what the device executes; their SHA-256 is stored with the counters (tools/collect_counters.py)
+DEVICE_SOURCES = ["minipath_amd/csrc/kernels.hip", "minipath_amd/csrc/mp_internal.h", "minipath_amd/csrc/device_tree.cpp"]
+
+
+def device_sources_sha256():
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in DEVICE_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def parse(argv=None):
@@ -73,6 +86,9 @@ def parse(argv=None):
     ap.add_argument("--balance", default="static", choices=["static", "lpt"],
                     help="N > 1: 'lpt' re-partitions the tiles over the ranks by the cost the warmup frames measured (opt-in)")
     ap.add_argument("--wavefront", action="store_true", help="with --depth N: staged evaluation (HBM path streams, sorted)")
+    ap.add_argument("--progressive", type=int, default=1, metavar="P",
+                    help="render every frame as P progressive passes of spp/P samples (BASELINE configs[4]'s shape): the running sums "
+                         "stay sharded on their GPUs, the framebuffer is gathered once per frame, after the last pass")
     ap.add_argument("--no-extension", action="store_true", help="skip the secondary measurements (teapot_c2, paths_depth8)")
     ap.add_argument("--check", action="store_true", help="compare a few tiles of the GPU frame with the oracle")
     args = ap.parse_args(argv)
@@ -101,10 +117,16 @@ def workload_key(scene_name, w, h, spp, tile, depth, traversal):
 
 
 def load_counters(key):
+    """(counters of the workload or None, stale): stale = the counters were collected from other device sources than the tree's
+    (SHA-256 over DEVICE_SOURCES differs): they are then NOT used for valu_issue_frac / salu_issue_frac / traffic."""
     try:
-        return json.load(open(COUNTERS)).get(key)
+        d = json.load(open(COUNTERS))
     except Exception:
-        return None
+        return None, False
+    c = d.get(key)
+    if c is None:
+        return None, False
+    return c, d.get("_meta", {}).get("device_sources_sha256") != device_sources_sha256()
 
 
 def make_scene(mp, ctx, scene_arg, detail):
@@ -218,6 +240,7 @@ def main():
         """W untimed + exactly K timed frames bracketed by barrier + synchronize.  Returns a dict of whole-job numbers."""
         frame = DistributedFrame(scene_, cam_, st_, rank, world)
         events = []
+        seg_acc = None
         for _ in range(warmup):
             frame.step(want_u8=True)
         frame.flush()
@@ -230,7 +253,18 @@ def main():
         img = None
         for _ in range(steps):
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            out_img, _ = frame.step(want_u8=True, kernel_events=ev)  # N > 1: the previous frame's image (pipelined gather)
+            if args.progressive > 1:  # P passes into the resident shard, one gather + un-tile at the end of the frame
+                spp_, per = st_.sample_count, -(-st_.sample_count // args.progressive)
+                ev[0].record()
+                nxt = 0
+                seg_acc = torch.zeros(1, dtype=torch.int64, device=dev)
+                while nxt < spp_:
+                    nxt = frame.render_pass(nxt, min(per, spp_ - nxt) if nxt + per < spp_ else 0)
+                    seg_acc += frame.renderer.segments  # on the stream: no host synchronisation between the passes
+                ev[1].record()
+                out_img, _ = frame.gather_image(spp_, want_u8=True)
+            else:
+                out_img, _ = frame.step(want_u8=True, kernel_events=ev)  # N > 1: the previous frame's image (pipelined gather)
             events.append(ev)
             img = out_img if out_img is not None else img
         last, _ = frame.flush()  # completes the last frame's gather + un-tile inside the timed region
@@ -238,7 +272,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         k_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)  # HIP events on the launch stream
-        seg_local = int(frame.renderer.segments.item())  # Object::intersect calls of this rank's last launch
+        seg_local = int((seg_acc if args.progressive > 1 else frame.renderer.segments).item())  # Object::intersect calls of this rank's last frame
         if world > 1:
             red = torch.tensor([elapsed, k_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(red, op=dist.ReduceOp.MAX)
@@ -251,7 +285,8 @@ def main():
         return {"elapsed": elapsed, "kernel_ms": k_ms, "seg_local": seg_local, "seg_total": seg_total, "img": img, "tiles": frame.all_tiles}
 
     def roofline(kernel, m, b_ray, key, cu_count):
-        """SURVEY 8(d) algorithmic figure + the measured counters of the same workload (profiles/r02_counters.json)."""
+        """SURVEY 8(d) algorithmic figure + the measured counters of the same workload (profiles/r03_counters.json), the latter
+        only if they were collected from the device sources of this tree (otherwise "counters_stale": true and no derived figures)."""
         k_s = m["kernel_ms"] * 1e-3
         achieved = m["seg_local"] * b_ray / k_s / 1e9
         r = {
@@ -262,7 +297,10 @@ def main():
             "kernel_ms": m["kernel_ms"], "algorithmic_bytes_per_launch": m["seg_local"] * b_ray, "bytes_per_ray": b_ray,
             "traffic": None,
         }
-        c = load_counters(key) if world == 1 else None
+        c, stale = load_counters(key) if world == 1 else (None, False)
+        if c and stale:
+            r["counters_stale"] = True  # profiles/r03_counters.json predates the device sources: nothing derived from it
+            c = None
         if c:
             r["traffic"] = c.get("hbm_bytes_per_launch")
             if r["traffic"]:
@@ -277,7 +315,8 @@ def main():
                     r["valu_lane_utilisation"] = c["valu_lane_utilisation"]
                 if c.get("SQ_INSTS_SALU"):  # one scalar ALU per CU, one instruction per cycle
                     r["salu_issue_frac"] = c["SQ_INSTS_SALU"] / (cu_count * SHADER_CLOCK_HZ * k_s)
-            r["counters_from"] = c.get("source", "profiles/r02_counters.json")
+            r["counters_stale"] = False
+            r["counters_from"] = c.get("source", "profiles/r03_counters.json")
         return r
 
     total_samples = args.width * args.height * args.spp
@@ -330,7 +369,8 @@ def main():
                             + ("depth1 (reference semantics: primary ray + |d.n|, worker.rs:51-66)" if args.depth == 0 else
                                f"paths max_depth {args.depth} (build-defined extension, no reference counterpart; rays = traced segments)"),
                 "rays_per_step": m["seg_total"],
-                "parallelism": f"tiles round-robin over {world} rank(s)" + (" + RCCL gather to rank 0" if world > 1 else ""),
+                "parallelism": f"tiles round-robin over {world} rank(s)" + (" + RCCL gather to rank 0" if world > 1 else "")
+                               + (f"; {args.progressive} progressive passes per frame, accumulators resident on their GPUs, one gather per frame" if args.progressive > 1 else ""),
             },
             "roofline": roofline(kname, m, b_ray, key, cu),
         }

@@ -315,15 +315,34 @@ int mp_render_tiles_device_ex(mp_ctx *ctx, const mp_scene *scene, const mp_camer
  * f32 frame and/or its color_to_image u8 frame (either may be NULL). */
 int mp_untile(mp_ctx *ctx, const mp_settings *settings, const mp_block *tiles, size_t n_tiles,
               const float *d_tiles_f32, float *d_image_f32, uint8_t *d_image_u8, void *stream);
+/* Preview of an unfinished MP_FLAG_ACCUMULATE tile buffer after samples_done (< sample_count) samples, scattered into an
+ * image-major frame like mp_untile; the buffer is only read.  BUILD-DEFINED (the reference's progressive consumer, gui.rs:216-224,
+ * re-renders with a smaller sample_count instead): pixel = running sum * (1.0f / (f32)samples_done), alpha = hits * the same
+ * (worker.rs:44 for the samples drawn so far); under MP_FLAG_CHUNKED_SUM (f32)((total + (f64)chunk sum) * (1.0 / (f64)samples_done)).
+ * samples_done == sample_count: the buffer already holds the means, plain mp_untile. */
+int mp_untile_preview(mp_ctx *ctx, const mp_settings *settings, const mp_block *tiles, size_t n_tiles,
+                      const float *d_tiles_f32, uint32_t samples_done, float *d_image_f32, uint8_t *d_image_u8, void *stream);
 /* One whole frame over n GPUs of this process, device-resident (SURVEY 8e in one process): rank r renders tiles r, r+n, ... of
- * the row-major tile grid in ONE launch on ctxs[r]'s own stream into its shard; the shards are copied to ctxs[0]'s device by
- * peer copies (hipMemcpyPeerAsync: every peer over its own xGMI link) on `stream` (a stream of ctxs[0]'s device) and scattered
- * there into d_image_f32 / d_image_u8 (image-major, either may be NULL).  Asynchronous: the frame is complete when `stream` is.
- * All samples of a pixel stay on one device, so the image does not depend on n.  *ray_segments (host, optional) receives the
- * Object::intersect calls of the frame for the reference semantics.  Contexts must be distinct; two may share a device. */
+ * the row-major tile grid in ONE launch on ctxs[r]'s own stream into its shard and sends the shard to ctxs[0]'s device on that
+ * same stream (hipMemcpyPeerAsync: n copies on n streams, every peer over its own xGMI link, overlapping the other ranks'
+ * renders); `stream` (a stream of ctxs[0]'s device) waits for the n copies and scatters the gathered tiles into d_image_f32 /
+ * d_image_u8 (image-major, either may be NULL).  Peer access is checked once per device pair (hipDeviceCanAccessPeer, both
+ * directions); without it the shard is staged through pinned host memory.  Asynchronous: the frame is complete when `stream`
+ * is.  All samples of a pixel stay on one device, so the image does not depend on n.  *ray_segments (host, optional) receives
+ * the Object::intersect calls of the frame for the reference semantics.  Contexts must be distinct; two may share a device.
+ * Frames on the same ctxs[0] are serialised; a context takes part in one multi-device frame at a time. */
 int mp_render_frame_multi(mp_ctx *const *ctxs, const mp_scene *const *scenes, int n, const mp_camera_sampler *sampler,
                           const mp_settings *settings, float *d_image_f32, uint8_t *d_image_u8, uint64_t *ray_segments,
                           void *stream);
+/* Progressive form (BASELINE configs[4]; SURVEY 8e: "accumulators stay sharded; gather only per displayed pass / at end"):
+ * settings carries MP_FLAG_ACCUMULATE and names the pass [pass_begin, pass_begin + pass_count).  Every rank adds the pass to the
+ * running state of ITS shard, which stays on its device between calls (pass_begin must continue the previous call's pass with
+ * the same settings, ranks and scenes; pass_begin 0 starts over).  gather = 0: nothing leaves the devices.  gather != 0: the
+ * shards are gathered and scattered as in mp_render_frame_multi -- after the last pass the finished frame (bit-identical to one
+ * mp_render_frame_multi), after an earlier pass a preview as mp_untile_preview defines it (the shards keep their state). */
+int mp_render_pass_multi(mp_ctx *const *ctxs, const mp_scene *const *scenes, int n, const mp_camera_sampler *sampler,
+                         const mp_settings *settings, int gather, float *d_image_f32, uint8_t *d_image_u8,
+                         uint64_t *ray_segments, void *stream);
 /* Rays traced (Object::intersect calls) and their wall time inside the last mp_render_tiles_device launch is
  * NOT measured here: the caller brackets the stream with events. */
 

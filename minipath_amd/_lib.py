@@ -225,6 +225,13 @@ SIGNATURES = {
         [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(SamplerStruct), C.POINTER(SettingsStruct), C.c_void_p,
          C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p],
     ),
+    "mp_render_pass_multi": (
+        C.c_int,
+        [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(SamplerStruct), C.POINTER(SettingsStruct), C.c_int, C.c_void_p,
+         C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p],
+    ),
+    "mp_untile_preview": (C.c_int, [C.c_void_p, C.POINTER(SettingsStruct), C.POINTER(Block), C.c_size_t, C.c_void_p, C.c_uint32, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]),
     "mp_render_progress": (C.c_int, [C.c_void_p, C.POINTER(Progress)]),
     "mp_render_is_finished": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "mp_render_elapsed_ns": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -122,17 +122,28 @@ struct mp_ctx {
     int acquire_slot(size_t tiles, size_t per_tile, WorkerSlot& out);
     void release_slot(const WorkerSlot& s);
     static void destroy_slot(WorkerSlot& s);
-    // Buffers of mp_render_frame_multi: this device's shard (tile-major), its stream and completion event; on the gathering
-    // device also the rank-major gather buffer and the event after which the shards may be overwritten by the next frame.
+    // Buffers of mp_render_frame_multi / mp_render_pass_multi.  As a rank: this device's shard (tile-major; between
+    // MP_FLAG_ACCUMULATE passes it holds the running per-pixel state and never leaves the device), the rank's stream -- render and
+    // the copy of the shard towards the gathering device are issued on it in order, so every rank's copy runs on its own stream
+    // (its own xGMI link) and overlaps the others -- and the event recorded after the copy.  As the gathering context (ctxs[0]):
+    // the rank-major gather buffer, the event after which it may be overwritten by the next frame's copies, and per peer device
+    // whether direct peer access works (checked once) or the shard is staged through pinned host memory.
     struct MultiBuf {
         float* d_shard = nullptr;
         size_t shard_cap = 0;  // floats
         hipStream_t stream = nullptr;
-        hipEvent_t rendered = nullptr;
+        hipEvent_t copied = nullptr;
+        float* h_stage = nullptr;  // pinned; only without peer access to the gathering device
+        size_t stage_cap = 0;
         float* d_gather = nullptr;
         size_t gather_cap = 0;
-        hipEvent_t gathered = nullptr;
-        bool gathered_valid = false;
+        hipEvent_t untiled = nullptr;
+        bool untiled_valid = false;
+        std::vector<int> peer;  // by device id: 0 = not asked yet, 1 = direct peer copies, 2 = staged through the host
+        // progressive accumulation: what the shard's running state belongs to, and the next sample it expects
+        uint64_t acc_seed = 0;
+        uint32_t acc_w = 0, acc_h = 0, acc_ts = 0, acc_spp = 0, acc_flags = 0, acc_depth = 0, acc_n = 0, acc_rank = 0, acc_next = 0;
+        const mp_scene* acc_scene = nullptr;
     } multi;
     std::mutex multi_mu;
     static constexpr size_t kTileLists = 32;
@@ -527,8 +538,9 @@ void mp_ctx_destroy(mp_ctx* ctx) {
     if (ctx->multi.stream) (void)hipStreamSynchronize(ctx->multi.stream);
     if (ctx->multi.d_shard) (void)hipFree(ctx->multi.d_shard);
     if (ctx->multi.d_gather) (void)hipFree(ctx->multi.d_gather);
-    if (ctx->multi.rendered) (void)hipEventDestroy(ctx->multi.rendered);
-    if (ctx->multi.gathered) (void)hipEventDestroy(ctx->multi.gathered);
+    if (ctx->multi.h_stage) (void)hipHostFree(ctx->multi.h_stage);
+    if (ctx->multi.copied) (void)hipEventDestroy(ctx->multi.copied);
+    if (ctx->multi.untiled) (void)hipEventDestroy(ctx->multi.untiled);
     if (ctx->multi.stream) (void)hipStreamDestroy(ctx->multi.stream);
     delete ctx;
 }
@@ -1051,23 +1063,30 @@ int mp_untile(mp_ctx* ctx, const mp_settings* settings, const mp_block* tiles, s
     });
 }
 
-int mp_render_frame_multi(mp_ctx* const* ctxs, const mp_scene* const* scenes, int n, const mp_camera_sampler* sampler,
-                          const mp_settings* settings, float* d_image_f32, uint8_t* d_image_u8, uint64_t* ray_segments,
-                          void* stream) {
-    return guarded([&]() -> int {
+namespace {
+
+// One pass (or whole frame) over n ranks, and optionally the gather + un-tile on ctxs[0]'s device.
+int render_multi_impl(mp_ctx* const* ctxs, const mp_scene* const* scenes, int n, const mp_camera_sampler* sampler,
+                      const mp_settings* settings, bool gather, float* d_image_f32, uint8_t* d_image_u8, uint64_t* ray_segments,
+                      void* stream) {
     if (!ctxs || !scenes || n < 1 || n > 64 || !sampler || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
-    if (settings->flags & (MP_FLAG_ACCUMULATE | MP_FLAG_WAVEFRONT)) return fail(MP_ERR_INVALID, "mp_render_frame_multi renders whole frames with the fused kernels");
+    if (settings->flags & MP_FLAG_WAVEFRONT) return fail(MP_ERR_INVALID, "the multi-device frame uses the fused kernels");
     for (int i = 0; i < n; i++) {
         if (!ctxs[i] || !scenes[i] || scenes[i]->ctx != ctxs[i]) return fail(MP_ERR_INVALID, "scenes[i] must live on ctxs[i]");
         for (int j = 0; j < i; j++)
             if (ctxs[j] == ctxs[i]) return fail(MP_ERR_INVALID, "every rank needs its own context (two contexts may share a device)");
     }
+    const bool acc = (settings->flags & MP_FLAG_ACCUMULATE) != 0;
+    const uint32_t p_begin = acc ? settings->pass_begin : 0u, p_end = p_begin + pass_samples(*settings);
+    const bool final_pass = p_end == settings->sample_count;
     const uint32_t ts = settings->tile_size;
     const std::vector<mp_block> all = tile_ordering(mp_block{0, 0, settings->width, settings->height}, ts, 0);
     const size_t per_rank = (all.size() + static_cast<size_t>(n) - 1) / static_cast<size_t>(n);
     const size_t tile_floats = static_cast<size_t>(ts) * ts * 4;
     hipStream_t st0 = static_cast<hipStream_t>(stream);
     mp_ctx* c0 = ctxs[0];
+    // Frames on the same gathering context are serialised: its gather buffer, events and peer table are one set.
+    std::lock_guard<std::mutex> lk0(c0->multi_mu);
     // gather buffer on device 0, rank-major: slot r*per_rank + k = k-th tile of rank r (tiles r, r+n, r+2n, ... of the grid)
     std::vector<mp_block> order(per_rank * static_cast<size_t>(n), mp_block{0, 0, 0, 0});
     std::vector<std::vector<mp_block>> shard(static_cast<size_t>(n));
@@ -1076,74 +1095,174 @@ int mp_render_frame_multi(mp_ctx* const* ctxs, const mp_scene* const* scenes, in
         order[r * per_rank + k] = all[t];
         shard[r].push_back(all[t]);
     }
-    {
+    if (gather) {
         DeviceGuard g(c0->device);
-        std::lock_guard<std::mutex> lk(c0->multi_mu);
         if (c0->multi.gather_cap < order.size() * tile_floats) {
+            if (c0->multi.untiled_valid) (void)hipEventSynchronize(c0->multi.untiled);  // the last un-tile still reads the old buffer
             if (c0->multi.d_gather) (void)hipFree(c0->multi.d_gather);
             c0->multi.d_gather = nullptr;
+            c0->multi.gather_cap = 0;
             MP_HIP(hipMalloc(reinterpret_cast<void**>(&c0->multi.d_gather), order.size() * tile_floats * 4));
             c0->multi.gather_cap = order.size() * tile_floats;
         }
-        if (!c0->multi.gathered) MP_HIP(hipEventCreateWithFlags(&c0->multi.gathered, hipEventDisableTiming));
+        if (!c0->multi.untiled) MP_HIP(hipEventCreateWithFlags(&c0->multi.untiled, hipEventDisableTiming));
+        // direct peer copies where the devices can reach each other (xGMI), staged through pinned host memory otherwise; asked once
+        int ndev = 0;
+        MP_HIP(hipGetDeviceCount(&ndev));
+        if (c0->multi.peer.size() < static_cast<size_t>(ndev)) c0->multi.peer.resize(static_cast<size_t>(ndev), 0);
+        for (int r = 1; r < n; r++) {
+            const int d = ctxs[r]->device;
+            if (d == c0->device || d < 0 || d >= ndev || c0->multi.peer[static_cast<size_t>(d)] != 0) continue;
+            int can01 = 0, can10 = 0;
+            bool direct = hipDeviceCanAccessPeer(&can01, c0->device, d) == hipSuccess && hipDeviceCanAccessPeer(&can10, d, c0->device) == hipSuccess &&
+                          can01 && can10;
+            if (direct) {  // both directions: the copy runs on the source device's stream and writes device 0's memory
+                hipError_t e1 = hipDeviceEnablePeerAccess(d, 0);
+                if (e1 == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e1 = hipSuccess; }
+                hipError_t e2;
+                {
+                    DeviceGuard gd(d);
+                    e2 = hipDeviceEnablePeerAccess(c0->device, 0);
+                    if (e2 == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e2 = hipSuccess; }
+                }
+                if (e1 != hipSuccess || e2 != hipSuccess) { (void)hipGetLastError(); direct = false; }
+            }
+            c0->multi.peer[static_cast<size_t>(d)] = direct ? 1 : 2;
+        }
     }
     uint64_t segs = 0;
-    // every rank renders its shard in one launch on its own stream (machinery.rs:51-116: the workers own their tiles)
-    for (int r = 0; r < n; r++) {
-        mp_ctx* c = ctxs[r];
-        if (shard[static_cast<size_t>(r)].empty()) continue;
-        DeviceGuard g(c->device);
-        std::lock_guard<std::mutex> lk(c->multi_mu);
-        if (!c->multi.stream) MP_HIP(hipStreamCreateWithFlags(&c->multi.stream, hipStreamNonBlocking));
-        if (!c->multi.rendered) MP_HIP(hipEventCreateWithFlags(&c->multi.rendered, hipEventDisableTiming));
-        if (c->multi.shard_cap < per_rank * tile_floats) {
-            (void)hipStreamSynchronize(c->multi.stream);
-            if (c->multi.d_shard) (void)hipFree(c->multi.d_shard);
-            c->multi.d_shard = nullptr;
-            MP_HIP(hipMalloc(reinterpret_cast<void**>(&c->multi.d_shard), per_rank * tile_floats * 4));
-            c->multi.shard_cap = per_rank * tile_floats;
-        }
-        // the previous frame's gather must have read this shard before it is overwritten
-        if (c0->multi.gathered_valid) MP_HIP(hipStreamWaitEvent(c->multi.stream, c0->multi.gathered, 0));
-        const mp_block* d_tiles = nullptr;
-        mp_ctx::TileListRef keep;
-        int rc = c->device_tiles(shard[static_cast<size_t>(r)].data(), shard[static_cast<size_t>(r)].size(), nullptr, keep, &d_tiles, nullptr);
-        if (rc) return rc;
-        rc = render_tiles_device(c, scenes[r], *sampler, *settings, d_tiles, shard[static_cast<size_t>(r)].size(), c->multi.d_shard, c->multi.stream);
-        if (rc) return rc;
-        MP_HIP(hipEventRecord(c->multi.rendered, c->multi.stream));
-        if (!(settings->flags & MP_FLAG_PATHS))
-            for (const mp_block& b : shard[static_cast<size_t>(r)]) segs += static_cast<uint64_t>(b.max_x - b.min_x) * (b.max_y - b.min_y) * settings->sample_count;
-    }
-    if (ray_segments) *ray_segments = segs;  // reference semantics only (0 with MP_FLAG_PATHS: use mp_render_tiles_device_counted)
-    // gather: every peer's shard travels over its own link to device 0, then one un-tile kernel there
-    DeviceGuard g0(c0->device);
-    for (int r = 1; r < n; r++)  // direct xGMI copies instead of staging through the host; "already enabled" / unsupported are fine
-        if (ctxs[r]->device != c0->device) {
-            (void)hipDeviceEnablePeerAccess(ctxs[r]->device, 0);
-            (void)hipGetLastError();
-        }
+    // every rank renders its shard in one launch on its own stream (machinery.rs:51-116: the workers own their tiles) and, when
+    // the frame is gathered, sends it to device 0 on that same stream: n copies on n streams, each peer over its own link
     for (int r = 0; r < n; r++) {
         mp_ctx* c = ctxs[r];
         const size_t nt = shard[static_cast<size_t>(r)].size();
         if (nt == 0) continue;
-        MP_HIP(hipStreamWaitEvent(st0, c->multi.rendered, 0));
-        MP_HIP(hipMemcpyPeerAsync(c0->multi.d_gather + static_cast<size_t>(r) * per_rank * tile_floats, c0->device, c->multi.d_shard, c->device,
-                                  nt * tile_floats * 4, st0));
+        DeviceGuard g(c->device);
+        std::unique_lock<std::mutex> lk(c->multi_mu, std::defer_lock);
+        if (c != c0) lk.lock();
+        mp_ctx::MultiBuf& m = c->multi;
+        if (!m.stream) MP_HIP(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+        if (!m.copied) MP_HIP(hipEventCreateWithFlags(&m.copied, hipEventDisableTiming));
+        if (m.shard_cap < per_rank * tile_floats) {
+            MP_HIP(hipStreamSynchronize(m.stream));  // its render and its copy (issued in order on this stream) are done with the old buffer
+            if (m.d_shard) (void)hipFree(m.d_shard);
+            m.d_shard = nullptr;
+            m.shard_cap = 0;
+            m.acc_next = 0;
+            MP_HIP(hipMalloc(reinterpret_cast<void**>(&m.d_shard), per_rank * tile_floats * 4));
+            m.shard_cap = per_rank * tile_floats;
+        }
+        if (acc) {  // the running state in the shard must be this render's, at this sample
+            const bool same = m.acc_seed == settings->seed && m.acc_w == settings->width && m.acc_h == settings->height && m.acc_ts == ts &&
+                              m.acc_spp == settings->sample_count && m.acc_flags == (settings->flags & ~0u) && m.acc_depth == settings->max_depth &&
+                              m.acc_n == static_cast<uint32_t>(n) && m.acc_rank == static_cast<uint32_t>(r) && m.acc_scene == scenes[r];
+            if (p_begin != 0 && !(same && m.acc_next == p_begin))
+                return fail(MP_ERR_INVALID, "progressive pass does not continue the state this rank's shard holds (pass_begin must be the previous pass's end, same settings, same ranks)");
+            m.acc_seed = settings->seed; m.acc_w = settings->width; m.acc_h = settings->height; m.acc_ts = ts;
+            m.acc_spp = settings->sample_count; m.acc_flags = settings->flags; m.acc_depth = settings->max_depth;
+            m.acc_n = static_cast<uint32_t>(n); m.acc_rank = static_cast<uint32_t>(r); m.acc_scene = scenes[r];
+            m.acc_next = final_pass ? 0u : p_end;
+        } else {
+            m.acc_next = 0;
+        }
+        const mp_block* d_tiles = nullptr;
+        mp_ctx::TileListRef keep;
+        int rc = c->device_tiles(shard[static_cast<size_t>(r)].data(), nt, nullptr, keep, &d_tiles, nullptr);
+        if (rc) return rc;
+        rc = render_tiles_device(c, scenes[r], *sampler, *settings, d_tiles, nt, m.d_shard, m.stream);
+        if (rc) return rc;
+        if (!(settings->flags & MP_FLAG_PATHS))
+            for (const mp_block& b : shard[static_cast<size_t>(r)]) segs += static_cast<uint64_t>(b.max_x - b.min_x) * (b.max_y - b.min_y) * (p_end - p_begin);
+        if (!gather) continue;
+        // the previous frame's un-tile must have read the gather buffer before this frame's copy overwrites its slot
+        if (c0->multi.untiled_valid) MP_HIP(hipStreamWaitEvent(m.stream, c0->multi.untiled, 0));
+        float* dst = c0->multi.d_gather + static_cast<size_t>(r) * per_rank * tile_floats;
+        const size_t bytes = nt * tile_floats * 4;
+        const bool staged = c->device != c0->device && c0->multi.peer[static_cast<size_t>(c->device)] == 2;
+        if (!staged) {
+            MP_HIP(hipMemcpyPeerAsync(dst, c0->device, m.d_shard, c->device, bytes, m.stream));
+        } else {
+            if (m.stage_cap < per_rank * tile_floats) {
+                if (m.h_stage) (void)hipHostFree(m.h_stage);
+                m.h_stage = nullptr;
+                m.stage_cap = 0;
+                MP_HIP(hipHostMalloc(reinterpret_cast<void**>(&m.h_stage), per_rank * tile_floats * 4, hipHostMallocDefault));
+                m.stage_cap = per_rank * tile_floats;
+            }
+            MP_HIP(hipMemcpyAsync(m.h_stage, m.d_shard, bytes, hipMemcpyDeviceToHost, m.stream));
+        }
+        MP_HIP(hipEventRecord(m.copied, m.stream));
     }
-    MP_HIP(hipEventRecord(c0->multi.gathered, st0));
-    c0->multi.gathered_valid = true;
+    if (ray_segments) *ray_segments = segs;  // reference semantics only (0 with MP_FLAG_PATHS: use mp_render_tiles_device_counted)
+    if (!gather) return MP_OK;
+    DeviceGuard g0(c0->device);
+    for (int r = 0; r < n; r++) {
+        mp_ctx* c = ctxs[r];
+        const size_t nt = shard[static_cast<size_t>(r)].size();
+        if (nt == 0) continue;
+        MP_HIP(hipStreamWaitEvent(st0, c->multi.copied, 0));
+        if (c->device != c0->device && c0->multi.peer[static_cast<size_t>(c->device)] == 2)  // second leg of the staged copy
+            MP_HIP(hipMemcpyAsync(c0->multi.d_gather + static_cast<size_t>(r) * per_rank * tile_floats, c->multi.h_stage, nt * tile_floats * 4,
+                                  hipMemcpyHostToDevice, st0));
+    }
     const mp_block* d_order = nullptr;
     mp_ctx::TileListRef keep0;
     int rc = c0->device_tiles(order.data(), order.size(), nullptr, keep0, &d_order, nullptr);
     if (rc) return rc;
     std::string err;
+    // a gather before the last pass shows a preview: the running sums scaled by the samples drawn so far (the shards keep their state)
+    const uint32_t mode = (acc && !final_pass) ? ((settings->flags & MP_FLAG_CHUNKED_SUM) ? 2u : 1u) : 0u;
     rc = launch_untile(settings->width, settings->height, ts, d_order, static_cast<uint32_t>(order.size()), c0->multi.d_gather, d_image_f32,
-                       d_image_u8, st0, err);
+                       d_image_u8, st0, err, mode, p_end);
     if (rc) return fail(rc, err);
+    MP_HIP(hipEventRecord(c0->multi.untiled, st0));
+    c0->multi.untiled_valid = true;
     return MP_OK;
+}
+
+}  // namespace
+
+int mp_render_frame_multi(mp_ctx* const* ctxs, const mp_scene* const* scenes, int n, const mp_camera_sampler* sampler,
+                          const mp_settings* settings, float* d_image_f32, uint8_t* d_image_u8, uint64_t* ray_segments,
+                          void* stream) {
+    return guarded([&]() -> int {
+    if (settings && (settings->flags & MP_FLAG_ACCUMULATE)) return fail(MP_ERR_INVALID, "mp_render_frame_multi renders whole frames: progressive passes go through mp_render_pass_multi");
+    return render_multi_impl(ctxs, scenes, n, sampler, settings, true, d_image_f32, d_image_u8, ray_segments, stream);
     });
 }
+
+int mp_render_pass_multi(mp_ctx* const* ctxs, const mp_scene* const* scenes, int n, const mp_camera_sampler* sampler,
+                         const mp_settings* settings, int gather, float* d_image_f32, uint8_t* d_image_u8, uint64_t* ray_segments,
+                         void* stream) {
+    return guarded([&]() -> int {
+    if (settings && !(settings->flags & MP_FLAG_ACCUMULATE)) return fail(MP_ERR_INVALID, "mp_render_pass_multi takes MP_FLAG_ACCUMULATE settings (pass_begin / pass_count)");
+    return render_multi_impl(ctxs, scenes, n, sampler, settings, gather != 0, d_image_f32, d_image_u8, ray_segments, stream);
+    });
+}
+
+int mp_untile_preview(mp_ctx* ctx, const mp_settings* settings, const mp_block* tiles, size_t n_tiles, const float* d_tiles_f32,
+                      uint32_t samples_done, float* d_image_f32, uint8_t* d_image_u8, void* stream) {
+    return guarded([&]() -> int {
+    if (!ctx || !valid_settings(settings)) return fail(MP_ERR_INVALID, "bad argument");
+    if (samples_done == 0 || samples_done > settings->sample_count) return fail(MP_ERR_INVALID, "samples_done must be in 1..sample_count");
+    if (n_tiles == 0) return MP_OK;
+    if (!tiles || !d_tiles_f32) return fail(MP_ERR_INVALID, "NULL tiles/input");
+    if (n_tiles > 0xFFFFFFFFull) return fail(MP_ERR_INVALID, "too many tiles");
+    DeviceGuard g(ctx->device);
+    const mp_block* d_tiles = nullptr;
+    mp_ctx::TileListRef keep;
+    int rc = ctx->device_tiles(tiles, n_tiles, nullptr, keep, &d_tiles, nullptr);
+    if (rc) return rc;
+    std::string err;
+    // after the last sample the buffer holds the means already (the launch that reaches sample_count finalises)
+    const uint32_t mode = samples_done == settings->sample_count ? 0u : ((settings->flags & MP_FLAG_CHUNKED_SUM) ? 2u : 1u);
+    rc = launch_untile(settings->width, settings->height, settings->tile_size, d_tiles, static_cast<uint32_t>(n_tiles), d_tiles_f32,
+                       d_image_f32, d_image_u8, stream, err, mode, samples_done);
+    if (rc) fail(rc, err);
+    return rc;
+    });
+}
+
 
 int mp_render_tile(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler* sampler, const mp_settings* settings,
                    mp_block tile, float* rgba_f32, uint8_t* rgba_u8) {

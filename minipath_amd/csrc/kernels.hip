@@ -1771,8 +1771,13 @@ __device__ __forceinline__ uint8_t to_u8(float c) {
     return static_cast<uint8_t>(x);
 }
 
+// mode 0: the buffer holds finished pixels (means).  Preview of an unfinished MP_FLAG_ACCUMULATE buffer after k samples (the buffer
+// is only read): mode 1: slot = {sum, sum, sum, hits} -> {sum * inv_k, .., hits * inv_k} with inv_k = 1.0f / (float)k (worker.rs:44
+// for the samples drawn so far); mode 2 (MP_FLAG_CHUNKED_SUM): slot = {chunk sum, hits, f64 total} ->
+// (f32)((total + (f64)chunk sum) * (1.0 / (f64)k)), (f32)((f64)hits * (1.0 / (f64)k)) -- pixel_state_store's rule for k samples.
 __global__ __launch_bounds__(256) void untile_kernel(uint32_t width, uint32_t height, uint32_t ts, const mp_block* tiles,
-                                                     uint32_t n_tiles, const float* src, float* img_f32, uint8_t* img_u8) {
+                                                     uint32_t n_tiles, const float* src, float* img_f32, uint8_t* img_u8,
+                                                     uint32_t mode, float inv_k, double inv_k64) {
     const uint64_t per_tile = static_cast<uint64_t>(ts) * ts;
     const uint64_t n = per_tile * n_tiles;
     for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
@@ -1781,7 +1786,15 @@ __global__ __launch_bounds__(256) void untile_kernel(uint32_t width, uint32_t he
         const mp_block T = tiles[tile_i];
         const uint32_t x = T.min_x + p % ts, y = T.min_y + p / ts;
         if (x >= T.max_x || y >= T.max_y || x >= width || y >= height) continue;
-        const float4 v = *reinterpret_cast<const float4*>(src + i * 4);
+        float4 v = *reinterpret_cast<const float4*>(src + i * 4);
+        if (mode == 1u) {
+            const float m = v.x * inv_k;
+            v = make_float4(m, m, m, v.w * inv_k);
+        } else if (mode == 2u) {
+            const double tot = *reinterpret_cast<const double*>(src + i * 4 + 2) + static_cast<double>(v.x);
+            const float m = static_cast<float>(tot * inv_k64);
+            v = make_float4(m, m, m, static_cast<float>(static_cast<double>(v.y) * inv_k64));
+        }
         const size_t o = (static_cast<size_t>(y) * width + x) * 4;
         if (img_f32) *reinterpret_cast<float4*>(img_f32 + o) = v;
         if (img_u8) {
@@ -2073,12 +2086,15 @@ int launch_generate_rays(const mp_camera_sampler& s, uint32_t width, uint32_t sp
 }
 
 int launch_untile(uint32_t width, uint32_t height, uint32_t tile_size, const mp_block* d_tiles, uint32_t n_tiles,
-                  const float* d_tiles_f32, float* d_image_f32, uint8_t* d_image_u8, void* stream, std::string& err) {
+                  const float* d_tiles_f32, float* d_image_f32, uint8_t* d_image_u8, void* stream, std::string& err,
+                  uint32_t preview_mode, uint32_t preview_samples) {
     const uint64_t n = static_cast<uint64_t>(tile_size) * tile_size * n_tiles;
     if (n == 0) return MP_OK;
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>((n + 255) / 256, 8192));
+    const uint32_t k = std::max<uint32_t>(preview_samples, 1u);
     hipLaunchKernelGGL(untile_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), width, height, tile_size,
-                       d_tiles, n_tiles, d_tiles_f32, d_image_f32, d_image_u8);
+                       d_tiles, n_tiles, d_tiles_f32, d_image_f32, d_image_u8, preview_mode, 1.0f / static_cast<float>(k),
+                       1.0 / static_cast<double>(k));
     return check(hipGetLastError(), "untile_kernel launch", err);
 }
 

@@ -182,8 +182,11 @@ int launch_set_u64(unsigned long long* d_ptr, unsigned long long value, void* st
 int launch_generate_rays(const mp_camera_sampler& s, uint32_t width, uint32_t spp, uint64_t seed, mp_block block,
                          uint32_t sample, float* ox, float* oy, float* oz, float* dx, float* dy, float* dz, void* stream,
                          std::string& err);
+// preview_mode 0: finished pixels; 1 / 2: preview of an unfinished MP_FLAG_ACCUMULATE buffer (plain / MP_FLAG_CHUNKED_SUM state)
+// after preview_samples samples (untile_kernel)
 int launch_untile(uint32_t width, uint32_t height, uint32_t tile_size, const mp_block* d_tiles, uint32_t n_tiles,
-                  const float* d_tiles_f32, float* d_image_f32, uint8_t* d_image_u8, void* stream, std::string& err);
+                  const float* d_tiles_f32, float* d_image_f32, uint8_t* d_image_u8, void* stream, std::string& err,
+                  uint32_t preview_mode = 0, uint32_t preview_samples = 0);
 
 int launch_quantise(const float* d_rgba_f32, uint8_t* d_rgba_u8, uint64_t n_pixels, void* stream, std::string& err);
 

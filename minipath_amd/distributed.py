@@ -195,3 +195,30 @@ class DistributedFrame:
     def flush(self):
         """Complete the frame whose gather is still in flight (world > 1); returns its images on rank 0."""
         return self._complete()
+
+    # ---- progressive rendering (BASELINE configs[4]; SURVEY 8e: "accumulators stay sharded; gather only per displayed pass /
+    # at end") --------------------------------------------------------------------------------------------------------------
+    def render_pass(self, begin: int, count: int = 0) -> int:
+        """Adds samples [begin, begin+count) (count 0 = through the last) to the running per-pixel state of THIS rank's shard
+        (FrameRenderer.render_pass); purely local: nothing is exchanged.  Returns the next sample index.  All passes of one
+        progressive render go to the same shard buffer (no frame pipelining: call with no gather in flight)."""
+        assert self._pending is None, "flush() before a progressive pass"
+        self.renderer.tile_buf = self._shards[0]
+        self._frame = 0
+        return self.renderer.render_pass(begin, count)
+
+    def gather_image(self, samples_done: int, want_u8: bool = True):
+        """Collective: gathers the shards to rank 0 and un-tiles them there -- the finished frame if samples_done ==
+        sample_count (the last pass wrote the means), otherwise a preview of the samples drawn so far (mp_untile_preview); the
+        shards keep their running state either way.  Returns (f32 image, u8 image) on rank 0, (None, None) elsewhere."""
+        import torch.distributed as dist
+
+        total = int(self.settings.sample_count)
+        preview = None if samples_done >= total else int(samples_done)
+        src = self._shards[0]
+        if self.world == 1:
+            return self.renderer.untile(src, want_u8=want_u8, reuse=True, preview_samples=preview)
+        dist.gather(src, self._gather_views, dst=0)
+        if self.rank != 0:
+            return None, None
+        return self.renderer.untile(self._gather_buf, self._order, want_u8=want_u8, reuse=True, preview_samples=preview)

@@ -213,6 +213,31 @@ class MultiDeviceFrame:
         self.segments = seg.value
         return self.image, self.image_u8
 
+    def render_pass(self, begin: int, count: int = 0, gather: bool = True):
+        """Progressive form (mp_render_pass_multi; BASELINE configs[4]): adds samples [begin, begin+count) of
+        settings.sample_count (count 0 = through the last) to the running state of every rank's shard, which stays on its
+        device.  gather=False: nothing leaves the devices; returns the next sample index.  gather=True: also gathers and
+        un-tiles on scenes[0]'s device -- the finished frame after the last pass (bit-identical to render()), a preview
+        (running sums / samples so far) before; returns (next sample index, f32 image, u8 image)."""
+        import torch
+
+        total = int(self.settings.sample_count)
+        if not (0 <= begin < total) or count < 0 or begin + count > total:
+            raise ValueError("pass outside [0, sample_count)")
+        st = _lib.SettingsStruct.from_buffer_copy(self._st)
+        st.flags |= _lib.MP_FLAG_ACCUMULATE
+        st.pass_begin, st.pass_count = int(begin), int(count)
+        seg = C.c_uint64()
+        _lib.check(
+            _lib.lib().mp_render_pass_multi(
+                self._ctxs, self._hs, len(self.scenes), C.byref(self._sampler), C.byref(st), 1 if gather else 0, self.image.data_ptr(),
+                self.image_u8.data_ptr(), C.byref(seg), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream),
+            )
+        )
+        self.segments = seg.value
+        nxt = total if count == 0 else begin + count
+        return (nxt, self.image, self.image_u8) if gather else nxt
+
 
 def render_tile(scene: Scene, sampler: CameraSampler, settings: RenderSettings, tile: ScreenBlock):
     """Worker::render_tile (worker.rs:32-49), synchronous: returns (f32 means [h,w,4], u8 [h,w,4])."""
@@ -311,10 +336,13 @@ class FrameRenderer:
         )
         return total if count == 0 else begin + count
 
-    def untile(self, tile_buf=None, tiles: Optional[Sequence[ScreenBlock]] = None, want_u8: bool = True, reuse: bool = False):
+    def untile(self, tile_buf=None, tiles: Optional[Sequence[ScreenBlock]] = None, want_u8: bool = True, reuse: bool = False,
+               preview_samples: Optional[int] = None):
         """Tile-major -> image-major f32 (+ u8 via color_to_image) on the device.  Empty blocks in `tiles` (padding of
         equal-size multi-GPU shards) are skipped by the kernel.  reuse=True writes into this renderer's cached frame
-        buffers instead of allocating new ones (every pixel a tile covers is overwritten)."""
+        buffers instead of allocating new ones (every pixel a tile covers is overwritten).  preview_samples=k: the buffer is
+        the running state of an unfinished render_pass() sequence after k samples; the image is its preview
+        (mp_untile_preview: sums / k), the buffer is left as it is."""
         import torch
 
         w, h = self.settings.resolution
@@ -334,6 +362,14 @@ class FrameRenderer:
             img8 = torch.zeros((h, w, 4), dtype=torch.uint8, device=self.device) if want_u8 else None
             if reuse:
                 self._img, self._img8 = img, img8
+        if preview_samples is not None:
+            _lib.check(
+                _lib.lib().mp_untile_preview(
+                    self.ctx.handle, C.byref(self._st), tiles_c, len(tl), buf.data_ptr(), int(preview_samples), img.data_ptr(),
+                    img8.data_ptr() if img8 is not None else None, self._stream(),
+                )
+            )
+            return img, img8
         _lib.check(
             _lib.lib().mp_untile(
                 self.ctx.handle, C.byref(self._st), tiles_c, len(tl), buf.data_ptr(), img.data_ptr(),

@@ -41,6 +41,11 @@ def _worker(rank, world, port, res, ts, out_path):
     for i, t in enumerate(mine):  # "render": tile-major, row stride ts, clipped tiles leave the rest untouched
         ys, xs = np.mgrid[t.min_y:t.max_y, t.min_x:t.max_x]
         shard[i, : t.height(), : t.width()] = torch.from_numpy(_pattern(xs, ys))
+    # progressive shape ("accumulators stay sharded; gather only per displayed pass / at end"): three "passes" add to
+    # the rank's own shard; nothing is exchanged until the one gather below
+    for k in (1, 2, 3):
+        for i, t in enumerate(mine):
+            shard[i, : t.height(), : t.width(), 3] += float(k)
     cat = gather_shards(shard, plan, rank)
     if rank == 0:
         order = plan.gather_order
@@ -52,7 +57,9 @@ def _worker(rank, world, port, res, ts, out_path):
             img[t.min_y:t.max_y, t.min_x:t.max_x] = cat[slot, : t.height(), : t.width()].numpy()
             seen[t.min_y:t.max_y, t.min_x:t.max_x] += 1
         ys, xs = np.mgrid[0:h, 0:w]
-        ok = bool(np.array_equal(img, _pattern(xs, ys)) and np.all(seen == 1))
+        want = _pattern(xs, ys)
+        want[..., 3] += 6.0  # the three passes every rank accumulated locally
+        ok = bool(np.array_equal(img, want) and np.all(seen == 1))
         np.save(out_path, np.array([ok, len(tiles), plan.per_rank], dtype=np.int64))
     else:
         assert cat is None

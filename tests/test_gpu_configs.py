@@ -147,6 +147,20 @@ def test_c5_progressive_65536spp_depth16(golden, atrium):
     for (x0, y0, x1, y1), exp in zip(blocks, imgs):
         got = bits(buf[y0 - tile.min_y:y1 - tile.min_y, x0 - tile.min_x:x1 - tile.min_x])
         assert np.array_equal(got, exp), ((x0, y0, x1, y1), int(np.sum(got != exp)))
+    # the same tile through the staged pipeline (MP_FLAG_WAVEFRONT: HBM path streams, counting sort = stream compaction -- the
+    # "ray-sorted + stream-compacted wavefront" of configs[4]) at C5's own sample count and depth: same golden blocks, same segments
+    wf = mp.FrameRenderer(scene, cam, mp.RenderSettings(64, spp, res, seed=int(golden["seed"]), max_depth=depth, chunked_sum=True,
+                                                        wavefront=True), tiles=[tile])
+    nxt, wsegs = 0, 0
+    for count in (30001, 777, 0):
+        nxt = wf.render_pass(nxt, count)
+        wsegs += int(wf.segments.item())
+    torch.cuda.synchronize()
+    assert nxt == spp and wsegs == segs
+    wbuf = wf.tile_buf[0].cpu().numpy()
+    for (x0, y0, x1, y1), exp in zip(blocks, imgs):
+        got = bits(wbuf[y0 - tile.min_y:y1 - tile.min_y, x0 - tile.min_x:x1 - tile.min_x])
+        assert np.array_equal(got, exp), ("wavefront", (x0, y0, x1, y1), int(np.sum(got != exp)))
     # the reference's single f32 chain over the same 65 536 samples differs from the chunked mean only by its own rounding drift
     chain = mp.FrameRenderer(scene, cam, mp.RenderSettings(64, spp, res, seed=int(golden["seed"]), max_depth=depth), tiles=[tile])
     chain.render()

@@ -891,3 +891,24 @@ def test_bench_two_rank_rehearsal(balance):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["check_mismatches"] == 0
     assert d["config"]["rays_per_step"] == 320 * 200 * 16
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_progressive_rehearsal():
+    """BASELINE configs[4]'s shape through bench.py's N > 1 path (VERDICT r2 #4b): every frame = 3 ragged progressive passes, the
+    running sums stay in each rank's shard, ONE gather per frame after the last pass; two ranks share this box's GPU over gloo.
+    The gathered frame equals the oracle's single-pass frame (--check)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MP_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scene", "teapot", "--width", "320",
+           "--height", "200", "--spp", "40", "--depth", "3", "--progressive", "3", "--no-cpu-baseline", "--no-extension", "--check"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["check_mismatches"] == 0 and "3 progressive passes" in d["config"]["parallelism"]
+    assert 320 * 200 * 40 < d["config"]["rays_per_step"] <= 320 * 200 * 40 * 3

@@ -231,7 +231,6 @@ def test_multi_device_behind_the_c_abi(oracle, teapot_oracle_bvh, n):
     r renders tiles r::n, shards gathered to device 0 by peer copies, un-tile there.  On this one-GPU box the n contexts share
     device 0 (the library allows it for exactly this purpose); the images must equal the oracle's frame bit for bit."""
     import threading
-    import time
 
     import torch
 
@@ -241,14 +240,20 @@ def test_multi_device_behind_the_c_abi(oracle, teapot_oracle_bvh, n):
     res = (200, 136)
     st = mp.RenderSettings(16, 6, res, seed=SEED)
     of, ou8, *_ = teapot_oracle_bvh.render_image_mt(oracle.build_sampler(oracle.teapot_camera(), *res), res[0], res[1], 6, SEED, 16, 8)
-    # render(): callbacks from n worker threads
+    # render(): callbacks from n worker threads.  Every worker starts with a tile (machinery.rs:51-75): the first `started`
+    # callback of each worker thread waits at a barrier for the other workers' first callbacks, so no worker can drain the
+    # queue before the others have taken a batch (the queue holds at least 4 batches per worker); all n threads must show up
     lock, started, finished, threads = threading.Lock(), [], [], set()
+    gate = threading.Barrier(n)
 
     def on_start(b):
-        time.sleep(0.001)  # a slow callback, so that no single worker can drain the queue before the others have started
+        me = threading.get_ident()
         with lock:
+            first = me not in threads
+            threads.add(me)
             started.append(b)
-            threads.add(threading.get_ident())
+        if first:
+            gate.wait(timeout=60)
 
     def on_finish(b, snap):
         with lock:
@@ -260,7 +265,7 @@ def test_multi_device_behind_the_c_abi(oracle, teapot_oracle_bvh, n):
     assert np.array_equal(bits(prog.image_f32()), bits(of)) and np.array_equal(prog.image(), ou8)
     assert len(started) == len(finished) == 13 * 9 and len({(b.min_x, b.min_y) for b in started}) == 13 * 9
     assert sorted(f[1] for f in finished) == list(range(1, 13 * 9 + 1))
-    assert 2 <= len(threads) <= n  # the devices' workers share the queue (which worker gets which tile is a race, as in the reference)
+    assert len(threads) == n  # every device's worker took part (which worker gets which tile is a race, as in the reference)
     prog.close()
     # device-resident frame
     mf = mp.MultiDeviceFrame(scenes, cam, st)

@@ -270,6 +270,28 @@ def test_camera_left_right_up_down(oracle):
     assert rc.d[1] > 0.99
 
 
+def test_camera_centre_ray_within_the_references_own_bound(oracle):
+    """camera.rs:201-226 with the reference's OWN bound |centre.x|, |centre.z| < 1e-3, made deterministic: with a
+    pinhole (f_number = inf => lens_radius = focal / (2 N) = 0, camera.rs:139) the only randomness left is the film jitter of
+    +-0.5 px, and pixel (400, 300) of an 800 x 600 film lies 0.5 px off the optical axis, so the direction's x and z are at most
+    1 px * pixel_scale / focal = (24e-3 / 600) / 50e-3 = 8e-4 for EVERY draw: the 1e-3 bound must hold for all seeds."""
+    cam = _cam_yfwd_zup(oracle)
+    cam.f_number = float("inf")
+    s = oracle.build_sampler(cam, 800, 600)
+    assert s.lens_radius == 0.0
+    worst = 0.0
+    for key in range(3000):
+        rc = oracle.sample_ray(s, 400, 300, key)
+        worst = max(worst, abs(rc.d[0]), abs(rc.d[2]))
+        assert abs(rc.d[0]) < 1e-3 and abs(rc.d[2]) < 1e-3 and rc.d[1] > 0.99
+        assert list(rc.o) == [0.0, 0.0, 0.0]  # no lens offset: every ray leaves the camera centre
+    assert 5e-4 < worst <= 8.0001e-4  # the analytic extreme is approached, never exceeded
+    # the sign relations of the reference's test, same pinhole
+    rl, rr = oracle.sample_ray(s, 0, 300, 12), oracle.sample_ray(s, 799, 300, 13)
+    ru, rd = oracle.sample_ray(s, 400, 0, 14), oracle.sample_ray(s, 400, 599, 15)
+    assert rl.d[0] < -0.1 < 0.1 < rr.d[0] and ru.d[2] > 0.1 and rd.d[2] < -0.1
+
+
 def test_camera_relative_translation(oracle):
     """camera.rs:229-247."""
     cam = _cam_yfwd_zup(oracle)

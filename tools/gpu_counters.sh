@@ -3,7 +3,7 @@
 # One workload = one TAG: kernel-trace stats of a short bench run, then rocprofv3 PMC passes (each counter set in its own run of
 # `bench.py --steps 1 --warmup 0`, --pmc never combined with tracing) for the kernel whose name contains KERNEL_SUBSTR.
 # Results: gpurun_out/cnt_TAG_*.txt (summed per counter), gpurun_out/cnt_TAG_kernel_stats.csv.  tools/collect_counters.py turns
-# them into profiles/r02_counters.json, which bench.py reads for roofline.traffic / valu_issue_frac.
+# them into profiles/r03_counters.json, which bench.py reads for roofline.traffic / valu_issue_frac.
 TAG=${1:-run}; K=${2:-render_}; shift 2; R=$PWD; mkdir -p $R/gpurun_out; cd /tmp; export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/cnt_${TAG}_trace -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extension "$@" > $R/gpurun_out/cnt_${TAG}_bench.log 2>&1 || echo "trace run failed"
 cp $R/gpurun_out/cnt_${TAG}_trace/*/*_kernel_stats.csv $R/gpurun_out/cnt_${TAG}_kernel_stats.csv 2>/dev/null
