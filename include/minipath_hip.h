@@ -155,9 +155,24 @@ typedef struct {
     float bbox_min[3], bbox_max[3];
 } mp_bvh_desc;
 
-/* BUILD-DEFINED path extension (MP_FLAG_PATHS): grey diffuse material, indexed by TriangleShadingData.material.  The
- * reference carries `material: usize` in every HitRecord (geometry/mod.rs:78) but only ever writes 0 and never reads it. */
-typedef struct { float albedo, emission; } mp_material;
+/* BUILD-DEFINED path extension (MP_FLAG_PATHS): diffuse material, indexed by TriangleShadingData.material.  The reference carries
+ * `material: usize` and `texture_coords` in every HitRecord (geometry/mod.rs:78-79, interpolated at ray_bvh_intersection.rs:80-83)
+ * but only ever writes material 0 (building.rs:201) and reads neither.  Reflectance and emitted radiance per colour channel;
+ * texture = MP_TEXTURE_CHECKER reads HitRecord.texture_coords: albedo2 replaces albedo on the odd cells of a checkerboard,
+ * cell = floor(tex.x * texture_scale) + floor(tex.y * texture_scale), odd iff cell * 0.5 has a fractional part (NaN counts as odd).
+ * Operation by operation in oracle/minipath_oracle.c (render_sample_paths_impl).  A table of grey (r = g = b), untextured
+ * materials renders exactly as the scalar {albedo, emission} table of rounds 1-2 did.  Coloured / textured tables are not
+ * combined with MP_FLAG_CHUNKED_SUM (its 16-byte pixel state carries one channel): MP_ERR_UNSUPPORTED. */
+#define MP_TEXTURE_NONE 0u
+#define MP_TEXTURE_CHECKER 1u
+typedef struct {
+    float albedo[3];
+    float emission[3];
+    float albedo2[3];       /* MP_TEXTURE_CHECKER: reflectance of the odd cells */
+    uint32_t texture;       /* MP_TEXTURE_* */
+    float texture_scale;    /* checker cells per unit of texture coordinate */
+    uint32_t reserved;      /* 0 */
+} mp_material;
 /* Material ids (mp_scene_from_triangles_mat, mp_bvh_desc.tri_material, OBJ `usemtl`) must be below this: a scene's material
  * table has max id + 1 entries, so an unbounded id would size a table of gigabytes (MP_ERR_INVALID otherwise). */
 #define MP_MAX_MATERIALS 65536u

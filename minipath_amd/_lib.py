@@ -123,7 +123,35 @@ class BvhDesc(C.Structure):
 
 
 class Material(C.Structure):
-    _fields_ = [("albedo", C.c_float), ("emission", C.c_float)]
+    _fields_ = [("albedo", C.c_float * 3), ("emission", C.c_float * 3), ("albedo2", C.c_float * 3), ("texture", C.c_uint32),
+                ("texture_scale", C.c_float), ("reserved", C.c_uint32)]
+
+    @classmethod
+    def make(cls, entry) -> "Material":
+        """(albedo, emission) with scalars (grey) or rgb triples, or a dict {"albedo", "emission", "albedo2", "checker": cells per
+        unit of texture coordinate}."""
+        def rgb(x):
+            try:
+                v = [float(c) for c in x]
+            except TypeError:
+                v = [float(x)] * 3
+            if len(v) == 1:
+                v = v * 3
+            if len(v) != 3:
+                raise ValueError("a colour is a scalar or an (r, g, b) triple")
+            return (C.c_float * 3)(*v)
+
+        if isinstance(entry, dict):
+            a = entry.get("albedo", 0.75)
+            m = cls(rgb(a), rgb(entry.get("emission", 0.0)), rgb(entry.get("albedo2", a)), 0, 0.0, 0)
+            if entry.get("checker") is not None:
+                m.texture, m.texture_scale = MP_TEXTURE_CHECKER, float(entry["checker"])
+            return m
+        a, e = entry
+        return cls(rgb(a), rgb(e), rgb(a), 0, 0.0, 0)
+
+
+MP_TEXTURE_NONE, MP_TEXTURE_CHECKER = 0, 1
 
 
 class HitsSoA(C.Structure):

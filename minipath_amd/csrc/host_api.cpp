@@ -157,6 +157,21 @@ struct mp_ctx {
                      const uint32_t** d_order);
 };
 
+// default material of the build-defined path extension: grey 0.75, no emission, no texture
+inline mp_material default_material() {
+    mp_material m{};
+    for (int c = 0; c < 3; c++) m.albedo[c] = m.albedo2[c] = 0.75f;
+    return m;
+}
+// a table of grey (r = g = b), untextured materials runs the one-channel kernels (bit-identical to the three-channel ones)
+inline bool table_is_grey(const std::vector<mp_material>& t) {
+    for (const mp_material& m : t)
+        if (m.texture != MP_TEXTURE_NONE || std::memcmp(&m.albedo[0], &m.albedo[1], 4) != 0 || std::memcmp(&m.albedo[0], &m.albedo[2], 4) != 0 ||
+            std::memcmp(&m.emission[0], &m.emission[1], 4) != 0 || std::memcmp(&m.emission[0], &m.emission[2], 4) != 0)
+            return false;
+    return true;
+}
+
 struct mp_scene {
     mp_ctx* ctx = nullptr;
     HostBvh host;
@@ -189,7 +204,7 @@ struct mp_scene {
     std::vector<const mp_scene*> members;
     bool one_object = false;              // mp_scene_instances: every member is inst_of
     std::vector<float> inst_t;
-    std::vector<mp_material> materials{mp_material{0.75f, 0.0f}};  // build-defined path extension defaults
+    std::vector<mp_material> materials{default_material()};  // build-defined path extension defaults
     float sky = 1.0f;
     uint32_t material_count = 1;  // max TriangleShadingData.material + 1
     uint64_t device_bytes = 0;
@@ -428,7 +443,7 @@ int finish_scene(mp_ctx* ctx, std::unique_ptr<mp_scene> s, mp_scene** out) {
     for (uint32_t m : s->host.material) mc = std::max(mc, m);
     if (mc >= MP_MAX_MATERIALS) return fail(MP_ERR_INVALID, "material id out of range (MP_MAX_MATERIALS)");  // build_bvh / bvh_from_arrays reject these already
     s->material_count = mc + 1;
-    s->materials.assign(s->material_count, mp_material{0.75f, 0.0f});
+    s->materials.assign(s->material_count, default_material());
     if (!ctx) {  // host-only scene: build + export work, nothing is uploaded and nothing can be rendered
         *out = s.release();
         return MP_OK;
@@ -462,6 +477,8 @@ uint32_t pass_samples(const mp_settings& st) {
 int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_sampler& sampler, const mp_settings& st,
                         const mp_block* d_tiles, size_t n, float* d_out, void* stream, uint64_t* d_segments = nullptr,
                         const uint32_t* d_tile_order = nullptr, uint64_t* d_tile_cost = nullptr) {
+    if ((st.flags & MP_FLAG_PATHS) && (st.flags & MP_FLAG_CHUNKED_SUM) && scene->dev.materials_rgb)
+        return fail(MP_ERR_UNSUPPORTED, "coloured / textured materials are not combined with MP_FLAG_CHUNKED_SUM (its pixel state carries one channel)");
     RenderLaunch L;
     L.scene = scene->dev;
     L.scene.packet_stack_regs = ctx->packet_stack_regs.load();
@@ -759,8 +776,9 @@ int make_group(mp_ctx* ctx, const mp_scene* const* objects, const float* rotatio
     }
     // material table of the group: the first member's, padded with the default material up to the largest id any member uses
     s->materials = objects[0]->materials;
-    if (s->materials.size() < s->material_count) s->materials.resize(s->material_count, mp_material{0.75f, 0.0f});
+    if (s->materials.size() < s->material_count) s->materials.resize(s->material_count, default_material());
     s->sky = objects[0]->sky;
+    s->dev.materials_rgb = table_is_grey(s->materials) ? 0u : 1u;
     s->dev.inst_count = n;
     s->dev.has_pre = 0;
     if (ctx) {
@@ -823,8 +841,11 @@ int mp_scene_set_materials(mp_scene* scene, const mp_material* table, uint32_t n
     if (!scene || !table) return fail(MP_ERR_INVALID, "NULL argument");
     if (scene->dev.kind != 0u) return fail(MP_ERR_UNSUPPORTED, "materials belong to TriangleBvh scenes");
     if (n < scene->material_count) return fail(MP_ERR_INVALID, "material table shorter than the scene's material_count");
+    for (uint32_t i = 0; i < n; i++)
+        if (table[i].texture != MP_TEXTURE_NONE && table[i].texture != MP_TEXTURE_CHECKER) return fail(MP_ERR_INVALID, "unknown texture kind in the material table");
     scene->materials.assign(table, table + n);
     scene->sky = sky_radiance;
+    scene->dev.materials_rgb = table_is_grey(scene->materials) ? 0u : 1u;
     if (scene->ctx) {  // a new table for this scene; instanced scenes made earlier keep the one they were created with
         DeviceGuard g(scene->ctx->device);
         auto tb = std::make_shared<mp_scene::DevTable>();

@@ -1280,24 +1280,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 // alive are compacted (ballot + mbcnt) into the wave's LDS ray queue and traced by the 8-lane-group traversal.
 constexpr float kPathEps = 1e-4f;
 
+// HitRecord.texture_coords (geometry/mod.rs:78-79; BarycentricCoordinates::interpolate at ray_bvh_intersection.rs:80-83), x and y
+__device__ __forceinline__ void hit_tex(const DevScene& so, uint32_t prim, float u, float v, float& tx, float& ty) {
+    const uint32_t* vi = so.vidx + static_cast<size_t>(prim) * 3;
+    const float *t0 = so.vtex + 3 * static_cast<size_t>(vi[0]), *t1 = so.vtex + 3 * static_cast<size_t>(vi[1]),
+                *t2 = so.vtex + 3 * static_cast<size_t>(vi[2]);
+    const float w = 1.0f - u - v;
+    tx = t0[0] * w + t1[0] * u + t2[0] * v;
+    ty = t0[1] * w + t1[1] * u + t2[1] * v;
+}
+
 // One path vertex of the build-defined extension (oracle: render_sample_paths_impl), shared by the fused and the staged kernels so
 // that both evaluate the very same operations: `h` is the closest hit of segment `depth` along `r`.  Updates L / thr, and either
 // ends the path (returns false) or replaces `r` by the bounce ray drawn from `rng` (returns true).
-template <bool OBJ = false>
+// N = colour channels carried: 3 when some material of the table is coloured or textured (DevScene::materials_rgb), else 1 -- a grey
+// table makes the three channels the same number, so one is computed (same bits).  Material record = mp_material: albedo rgb,
+// emission rgb, albedo2 rgb, texture, texture_scale.
+template <bool OBJ, int N>
 __device__ __forceinline__ bool path_vertex(const DevScene& sc, const PacketHit& h, uint32_t depth, uint32_t max_depth, Rng& rng,
-                                            Ray& r, float& L, float& thr, bool& primary_hit, uint32_t inst = 0u) {
+                                            Ray& r, float (&L)[N], float (&thr)[N], bool& primary_hit, uint32_t inst = 0u) {
     if (h.prim == kNoPrim) {
-        L = L + thr * sc.sky;
+#pragma unroll
+        for (int c = 0; c < N; c++) L[c] = L[c] + thr[c] * sc.sky;
         return false;
     }
     if (depth == 1) primary_hit = true;
     float n[3];
     const uint32_t mat = OBJ ? object_normal(sc, inst, r, h.prim, h.u, h.v, n) : resolve_normal(sc, h.prim, h.u, h.v, n);
-    const float2 m = reinterpret_cast<const float2*>(sc.materials)[mat];  // {albedo, emission}
-    L = L + thr * m.y;
+    const float* m = sc.materials + static_cast<size_t>(mat) * 12;
+#pragma unroll
+    for (int c = 0; c < N; c++) L[c] = L[c] + thr[c] * m[3 + c];
     const float dn = r.dx * n[0] + r.dy * n[1] + r.dz * n[2];
     if (dn > 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-    thr = thr * m.x;
+    const float* alb = m;
+    if (N == 3 && as_u(m[9]) == MP_TEXTURE_CHECKER) {  // reads HitRecord.texture_coords; a Sphere member's are the origin (primitives.rs:45)
+        float tx = 0.0f, ty = 0.0f;
+        if (OBJ) {
+            DevScene so;
+            object_scene(sc, inst, so);
+            if (so.kind == 0u) hit_tex(so, h.prim, h.u, h.v, tx, ty);
+        } else {
+            hit_tex(sc, h.prim, h.u, h.v, tx, ty);
+        }
+        const float cell = floorf(tx * m[10]) + floorf(ty * m[10]);
+        const float half = cell * 0.5f;
+        if (half - floorf(half) != 0.0f) alb = m + 6;  // odd cell (NaN counts as odd): albedo2
+    }
+#pragma unroll
+    for (int c = 0; c < N; c++) thr[c] = thr[c] * alb[c];
     if (depth == max_depth) return false;
     const float hx = r.ox + r.dx * h.t, hy = r.oy + r.dy * h.t, hz = r.oz + r.dz * h.t;  // geometry/mod.rs:56-58
     float x1, x2;
@@ -1313,8 +1343,25 @@ __device__ __forceinline__ bool path_vertex(const DevScene& sc, const PacketHit&
     return true;
 }
 
-template <int S, bool OBJ>
+// worker.rs:40-44 for three colour channels (coloured / textured material tables; never with MP_FLAG_CHUNKED_SUM): the slot holds
+// {sum r, sum g, sum b, hit count} between MP_FLAG_ACCUMULATE launches
+__device__ __forceinline__ void pixel_state_load3(const RenderParams& P, size_t off, bool inpix, float (&acc)[3], float& cnt) {
+    acc[0] = acc[1] = acc[2] = 0.0f;
+    cnt = 0.0f;
+    if (P.carry_in && inpix) {
+        const float4 prev = *reinterpret_cast<const float4*>(P.out + off);
+        acc[0] = prev.x; acc[1] = prev.y; acc[2] = prev.z;
+        cnt = prev.w;
+    }
+}
+__device__ __forceinline__ void pixel_state_store3(const RenderParams& P, size_t off, const float (&acc)[3], float cnt) {
+    const float s = P.finalize ? P.inv_spp : 1.0f;  // worker.rs:44 ; x * 1.0f is x
+    *reinterpret_cast<float4*>(P.out + off) = make_float4(acc[0] * s, acc[1] * s, acc[2] * s, cnt * s);
+}
+
+template <int S, bool OBJ, bool RGB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void render_paths_kernel(RenderParams P) {
+    constexpr int N = RGB ? 3 : 1;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : 2;
     constexpr int BH = 64 / S / BW;
@@ -1339,8 +1386,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         const bool inpix = px < T.max_x && py < T.max_y;
         if (__ballot(inpix) == 0) continue;
         const size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
-        float acc, cnt;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
-        pixel_state_load(P, off, inpix, sub == 0, acc, cnt);
+        float acc[N], cnt;  // pixel_sum (r=g=b for a grey table: one channel) and alpha (worker.rs:40)
+        if (RGB) pixel_state_load3(P, off, inpix, reinterpret_cast<float (&)[3]>(acc[0]), cnt);
+        else pixel_state_load(P, off, inpix, sub == 0, acc[0], cnt);
         // passes are aligned to multiples of S in the absolute sample index, so that a chunk boundary (MP_FLAG_CHUNKED_SUM) never
         // falls inside a pass; lanes outside [s_begin, s_end) add +0.0, which is exact
         for (uint32_t s0 = P.s_begin & ~static_cast<uint32_t>(S - 1); s0 < P.s_end; s0 += S) {
@@ -1354,7 +1402,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 rng_seed(rng, sample_key(P.gen, px, py, s));
                 sample_ray_rng(P.gen, px, py, rng, r);
             }
-            float L = 0.0f, thr = 1.0f;
+            float L[N], thr[N];
+#pragma unroll
+            for (int c = 0; c < N; c++) { L[c] = 0.0f; thr[c] = 1.0f; }
             bool alive = act, primary_hit = false;
             PacketHit h;
             for (uint32_t depth = 1; depth <= P.max_depth; depth++) {
@@ -1378,13 +1428,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                     h.t = gh.t; h.u = gh.u; h.v = gh.v; h.prim = gh.prim;
                     hinst = gh.inst;
                 }
-                if (alive) alive = path_vertex<OBJ>(P.scene, h, depth, P.max_depth, rng, r, L, thr, primary_hit, hinst);
+                if (alive) alive = path_vertex<OBJ, N>(P.scene, h, depth, P.max_depth, rng, r, L, thr, primary_hit, hinst);
             }
             cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
-            add_samples_in_order<S>(acc, L, lane);
-            if (P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) chunk_flush(P, off, inpix && sub == 0, acc);
+#pragma unroll
+            for (int c = 0; c < N; c++) add_samples_in_order<S>(acc[c], L[c], lane);
+            if (!RGB && P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) chunk_flush(P, off, inpix && sub == 0, acc[0]);
         }
-        if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
+        if (inpix && sub == 0) {
+            if (RGB) pixel_state_store3(P, off, reinterpret_cast<const float (&)[3]>(acc[0]), cnt);
+            else pixel_state_store(P, off, acc[0], cnt);
+        }
         if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
     }
     if (lane == 0 && P.segments && segs) atomicAdd(P.segments, segs);
@@ -1403,8 +1457,8 @@ constexpr uint32_t kDirBins = 512;  // 8 octants x 8 x 8 cells of the octahedral
 struct WfState {
     uint64_t* rng;       // 4 rows x n
     float* ray;          // 6 rows x n : origin, unit direction
-    float* thr;          // n
-    float* L;            // n
+    float* thr;          // nchan rows x n (nchan = 3 for a coloured / textured material table, else 1)
+    float* L;            // nchan rows x n
     float* hit_t;        // n
     uint32_t* hit_prim;  // n
     float* hit_u;        // n
@@ -1415,7 +1469,7 @@ struct WfState {
     uint32_t* hist;      // nbins + 1 : per-key counts of the segment being generated ; [nbins] unused
     uint32_t* offs;      // nbins + 1 : exclusive scan of hist ; [nbins] = number of live paths
     uint32_t* cursor;    // nbins
-    uint32_t n, nbins;
+    uint32_t n, nbins, nchan;
 };
 constexpr uint32_t kWfAlive = 1u, kWfPrimaryHit = 2u, kWfValid = 4u;
 
@@ -1497,8 +1551,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                     P.st.ray[0 * static_cast<size_t>(n) + p] = r.ox; P.st.ray[1 * static_cast<size_t>(n) + p] = r.oy;
                     P.st.ray[2 * static_cast<size_t>(n) + p] = r.oz; P.st.ray[3 * static_cast<size_t>(n) + p] = r.dx;
                     P.st.ray[4 * static_cast<size_t>(n) + p] = r.dy; P.st.ray[5 * static_cast<size_t>(n) + p] = r.dz;
-                    P.st.thr[p] = 1.0f;
-                    P.st.L[p] = 0.0f;
+                    for (uint32_t c = 0; c < P.st.nchan; c++) {
+                        P.st.thr[c * static_cast<size_t>(n) + p] = 1.0f;
+                        P.st.L[c * static_cast<size_t>(n) + p] = 0.0f;
+                    }
                     P.st.hit_t[p] = h.t; P.st.hit_prim[p] = h.prim; P.st.hit_u[p] = h.u; P.st.hit_v[p] = h.v;
                 }
             }
@@ -1508,6 +1564,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 }
 
 // Stage 2: one thread per path: shade the hit of segment P.depth, draw the bounce ray, count it under its sort key.
+template <int N>
 __global__ __launch_bounds__(256) void wf_vertex_kernel(WfParams P) {
     const uint32_t n = P.st.n;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
@@ -1523,13 +1580,15 @@ __global__ __launch_bounds__(256) void wf_vertex_kernel(WfParams P) {
         r.ix = r.iy = r.iz = 0.0f;  // not used by path_vertex
         PacketHit h;
         h.t = P.st.hit_t[p]; h.prim = P.st.hit_prim[p]; h.u = P.st.hit_u[p]; h.v = P.st.hit_v[p];
-        float L = P.st.L[p], thr = P.st.thr[p];
+        float L[N], thr[N];
+#pragma unroll
+        for (int c = 0; c < N; c++) { L[c] = P.st.L[c * static_cast<size_t>(n) + p]; thr[c] = P.st.thr[c * static_cast<size_t>(n) + p]; }
         bool primary = (fl & kWfPrimaryHit) != 0u;
-        const bool alive = path_vertex(P.scene, h, P.depth, P.max_depth, rng, r, L, thr, primary);
+        const bool alive = path_vertex<false, N>(P.scene, h, P.depth, P.max_depth, rng, r, L, thr, primary);
         fl = (fl & ~(kWfAlive | kWfPrimaryHit)) | (alive ? kWfAlive : 0u) | (primary ? kWfPrimaryHit : 0u);
         P.st.flags[p] = fl;
-        P.st.L[p] = L;
-        P.st.thr[p] = thr;
+#pragma unroll
+        for (int c = 0; c < N; c++) { P.st.L[c * static_cast<size_t>(n) + p] = L[c]; P.st.thr[c * static_cast<size_t>(n) + p] = thr[c]; }
         if (alive) {
             P.st.rng[0 * static_cast<size_t>(n) + p] = rng.s0; P.st.rng[1 * static_cast<size_t>(n) + p] = rng.s1;
             P.st.rng[2 * static_cast<size_t>(n) + p] = rng.s2; P.st.rng[3 * static_cast<size_t>(n) + p] = rng.s3;
@@ -1634,6 +1693,22 @@ __global__ __launch_bounds__(256) void wf_accumulate_kernel(WfParams P) {
         const mp_block T = P.tiles[tile_l];
         if (!(T.min_x + x < T.max_x && T.min_y + y < T.max_y)) continue;
         float* o = P.out + (static_cast<size_t>(P.tile_base + tile_l) * ts * ts + q) * 4;
+        if (P.st.nchan == 3u) {  // coloured / textured material table: slot = {sum r, sum g, sum b, hit count}; never chunked
+            float a3[3] = {0.0f, 0.0f, 0.0f}, c3 = 0.0f;
+            if (P.carry_in) {
+                const float4 prev = *reinterpret_cast<const float4*>(o);
+                a3[0] = prev.x; a3[1] = prev.y; a3[2] = prev.z; c3 = prev.w;
+            }
+            const uint32_t ns3 = min(P.sc, P.s_end - P.s0);
+            const uint32_t pb3 = i * P.sc;
+            for (uint32_t sl = 0; sl < ns3; sl++) {
+                for (uint32_t c = 0; c < 3u; c++) a3[c] += P.st.L[c * static_cast<size_t>(P.st.n) + pb3 + sl];
+                c3 += (P.st.flags[pb3 + sl] & kWfPrimaryHit) ? 1.0f : 0.0f;
+            }
+            const float sc3 = P.finalize ? P.inv_spp : 1.0f;
+            *reinterpret_cast<float4*>(o) = make_float4(a3[0] * sc3, a3[1] * sc3, a3[2] * sc3, c3 * sc3);
+            continue;
+        }
         float acc = 0.0f, cnt = 0.0f;
         double tot = 0.0;  // MP_FLAG_CHUNKED_SUM: slot = {chunk sum, hit count, f64 total} (pixel_state_load)
         if (P.carry_in) {
@@ -1890,15 +1965,21 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         const uint32_t nspp = L.pass_end - L.pass_begin;  // samples per pixel in this launch
         const int S = nspp >= 8 ? 8 : nspp >= 4 ? 4 : nspp >= 2 ? 2 : 1;  // 16 in flight measured slower here (teapot depth 8: 17.1 vs 15.7 ms)
         const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want * S, static_cast<uint64_t>(L.cu_count) * per_cu));
-        if (L.scene.inst_count != 0u) {  // object group: every segment is walked member by member
-            if (S == 8) hipLaunchKernelGGL((render_paths_kernel<8, true>), dim3(grid), dim3(256), lds, st, P);
-            else if (S == 4) hipLaunchKernelGGL((render_paths_kernel<4, true>), dim3(grid), dim3(256), lds, st, P);
-            else if (S == 2) hipLaunchKernelGGL((render_paths_kernel<2, true>), dim3(grid), dim3(256), lds, st, P);
-            else hipLaunchKernelGGL((render_paths_kernel<1, true>), dim3(grid), dim3(256), lds, st, P);
-        } else if (S == 8) hipLaunchKernelGGL((render_paths_kernel<8, false>), dim3(grid), dim3(256), lds, st, P);
-        else if (S == 4) hipLaunchKernelGGL((render_paths_kernel<4, false>), dim3(grid), dim3(256), lds, st, P);
-        else if (S == 2) hipLaunchKernelGGL((render_paths_kernel<2, false>), dim3(grid), dim3(256), lds, st, P);
-        else hipLaunchKernelGGL((render_paths_kernel<1, false>), dim3(grid), dim3(256), lds, st, P);
+#define MP_LAUNCH_PATHS(SV)                                                                                                  \
+    do {                                                                                                                     \
+        if (L.scene.inst_count != 0u) {  /* object group: every segment is walked member by member */                        \
+            if (rgb) hipLaunchKernelGGL((render_paths_kernel<SV, true, true>), dim3(grid), dim3(256), lds, st, P);           \
+            else hipLaunchKernelGGL((render_paths_kernel<SV, true, false>), dim3(grid), dim3(256), lds, st, P);              \
+        } else if (rgb) hipLaunchKernelGGL((render_paths_kernel<SV, false, true>), dim3(grid), dim3(256), lds, st, P);       \
+        else hipLaunchKernelGGL((render_paths_kernel<SV, false, false>), dim3(grid), dim3(256), lds, st, P);                 \
+    } while (0)
+        const bool rgb = L.scene.materials_rgb != 0u;  // a coloured / textured material table: three channels
+        if (rgb && L.chunked) { err = "coloured / textured materials are not combined with MP_FLAG_CHUNKED_SUM"; return MP_ERR_UNSUPPORTED; }
+        if (S == 8) MP_LAUNCH_PATHS(8);
+        else if (S == 4) MP_LAUNCH_PATHS(4);
+        else if (S == 2) MP_LAUNCH_PATHS(2);
+        else MP_LAUNCH_PATHS(1);
+#undef MP_LAUNCH_PATHS
         return check(hipGetLastError(), "render_paths_kernel launch", err);
     }
     if (L.traversal == 1 || L.scene.inst_count != 0u) {  // object groups are walked member by member by the 8-lane groups
@@ -1976,9 +2057,13 @@ int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::stri
     if (per_tile > (1ull << 28)) { err = "tile_size too large for the staged path evaluation"; return MP_ERR_UNSUPPORTED; }
     const uint32_t tb = static_cast<uint32_t>(std::max<uint64_t>(1, std::min<uint64_t>(L.n_tiles, (1ull << 21) / per_tile)));
     const uint32_t n_max = static_cast<uint32_t>(per_tile * tb), nbins = tb * kDirBins;
-    // workspace: rng 32 + ray 24 + thr, L 8 + hit 16 + flags, key, idx 12 = 92 bytes per path, stream-ordered allocation
+    // workspace: rng 32 + ray 24 + thr, L 8 (24 for three channels) + hit 16 + flags, key, idx 12 = 92 (108) bytes per path,
+    // stream-ordered allocation
+    const uint32_t nchan = L.scene.materials_rgb ? 3u : 1u;
+    if (nchan == 3u && L.chunked) { err = "coloured / textured materials are not combined with MP_FLAG_CHUNKED_SUM"; return MP_ERR_UNSUPPORTED; }
+    P.st.nchan = nchan;
     const size_t n64 = (static_cast<size_t>(n_max) + 63) & ~static_cast<size_t>(63);
-    const size_t bytes = n64 * 92 + (static_cast<size_t>(nbins) + 64) * 4 * 3;
+    const size_t bytes = n64 * (84 + 8 * nchan) + (static_cast<size_t>(nbins) + 64) * 4 * 3;
     unsigned char* ws = nullptr;
     int rc = check(hipMallocAsync(reinterpret_cast<void**>(&ws), bytes, st), "hipMallocAsync(path state)", err);
     if (rc) return rc;
@@ -1986,8 +2071,8 @@ int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::stri
     auto take = [&](size_t b) { unsigned char* r = w; w += b; return r; };
     P.st.rng = reinterpret_cast<uint64_t*>(take(n64 * 32));
     P.st.ray = reinterpret_cast<float*>(take(n64 * 24));
-    P.st.thr = reinterpret_cast<float*>(take(n64 * 4));
-    P.st.L = reinterpret_cast<float*>(take(n64 * 4));
+    P.st.thr = reinterpret_cast<float*>(take(n64 * 4 * nchan));
+    P.st.L = reinterpret_cast<float*>(take(n64 * 4 * nchan));
     P.st.hit_t = reinterpret_cast<float*>(take(n64 * 4));
     P.st.hit_prim = reinterpret_cast<uint32_t*>(take(n64 * 4));
     P.st.hit_u = reinterpret_cast<float*>(take(n64 * 4));
@@ -2029,7 +2114,8 @@ int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::stri
             const uint32_t gper = std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / glds));
             for (uint32_t depth = 1; depth <= L.max_depth; depth++) {
                 P.depth = depth;
-                hipLaunchKernelGGL(wf_vertex_kernel, dim3(flat_grid), dim3(256), 0, st, P);
+                if (nchan == 3u) hipLaunchKernelGGL(wf_vertex_kernel<3>, dim3(flat_grid), dim3(256), 0, st, P);
+                else hipLaunchKernelGGL(wf_vertex_kernel<1>, dim3(flat_grid), dim3(256), 0, st, P);
                 if (depth == L.max_depth) break;
                 hipLaunchKernelGGL(wf_scan_kernel, dim3(1), dim3(1024), 0, st, P);
                 hipLaunchKernelGGL(wf_scatter_kernel, dim3(flat_grid), dim3(256), 0, st, P);

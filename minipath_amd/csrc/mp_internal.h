@@ -122,7 +122,8 @@ struct DevScene {
     const uint32_t* pkt_valid = nullptr;
     const uint32_t* vidx = nullptr;  // packets*8*3
     const float* vtex = nullptr;     // nv*3
-    const float* materials = nullptr;  // build-defined path extension: {albedo, emission} per material id (device)
+    const float* materials = nullptr;  // build-defined path extension: mp_material records (12 dwords) per material id (device)
+    uint32_t materials_rgb = 0;        // ... some material is coloured or textured: three-channel path kernels
     float sky = 1.0f;                  // ... and the sky radiance
     uint32_t inst_count = 0;           // build-defined object group: number of members; 0 = plain BVH
     const struct DevObject* objects = nullptr;  // ... and their descriptors (device)

@@ -103,9 +103,11 @@ class TriangleBvh:
         return cls(h, ctx)
 
     def set_materials(self, table, sky: float = 1.0) -> None:
-        """Material table [(albedo, emission), ...] and sky radiance of the build-defined path extension."""
-        t = [(float(a), float(e)) for a, e in table]
-        arr = (_lib.Material * max(len(t), 1))(*[_lib.Material(a, e) for a, e in t])
+        """Material table and sky radiance of the build-defined path extension.  Entries: (albedo, emission) with scalars (grey)
+        or (r, g, b) triples, or a dict {"albedo", "emission", "albedo2", "checker": cells per unit of texture coordinate} -- a
+        procedural checkerboard over HitRecord.texture_coords (geometry/mod.rs:78-79)."""
+        t = [_lib.Material.make(e) for e in table]
+        arr = (_lib.Material * max(len(t), 1))(*t)
         _lib.check(_lib.lib().mp_scene_set_materials(self.handle, arr, len(t), C.c_float(sky)))
 
     def material_name(self, i: int) -> Optional[str]:

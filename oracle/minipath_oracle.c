@@ -854,7 +854,8 @@ static mpo_bvh *bvh_alloc(uint32_t nv, const float *nrm, const float *tex) {
     if (nrm) memcpy(b->vnormal, nrm, (size_t)nv * 3 * sizeof(float));
     if (tex) memcpy(b->vtex, tex, (size_t)nv * 3 * sizeof(float));
     b->mats = malloc(sizeof(mpo_material));
-    b->mats[0].albedo = MPO_PATH_ALBEDO; b->mats[0].emission = 0.0f;
+    memset(&b->mats[0], 0, sizeof(mpo_material));
+    for (int k = 0; k < 3; k++) b->mats[0].albedo[k] = b->mats[0].albedo2[k] = MPO_PATH_ALBEDO;
     b->n_mats = 1;
     b->sky = 1.0f;
     return b;
@@ -1435,15 +1436,20 @@ void mpo_render_tile_sphere(const float center[3], float radius, const mpo_sampl
 }
 
 /* ---- build-defined path extension (NO reference counterpart: the reference has no bounce loop) --------
- * Diffuse grey surfaces with a material table {albedo, emission} indexed by TriangleShadingData.material (mod.rs:44; always 0
- * in the reference, building.rs:201) under a uniform sky of radiance `sky`; defaults: one material {0.75, 0}, sky = 1.
+ * Diffuse surfaces with a material table {albedo rgb, emission rgb, checker texture} indexed by TriangleShadingData.material
+ * (mod.rs:44; always 0 in the reference, building.rs:201) under a uniform sky of radiance `sky`; defaults: one grey material
+ * {0.75, 0}, sky = 1.  Every operation below is per colour channel c (r, g, b); a table of grey, untextured materials makes the
+ * three channels the same number, which is the round-1/2 definition bit for bit.
  * Paths of at most max_depth segments:
- *   L = 0, throughput = 1; for depth = 1..max_depth: trace; miss -> L = L + throughput * sky, stop;
- *   hit -> m = material of the triangle; L = L + throughput * emission[m]; n = shading normal turned against the ray;
- *   throughput *= albedo[m]; at depth == max_depth stop;
+ *   L = 0, throughput = 1; for depth = 1..max_depth: trace; miss -> L[c] = L[c] + throughput[c] * sky, stop;
+ *   hit -> m = material of the triangle; L[c] = L[c] + throughput[c] * emission[m][c]; n = shading normal turned against the ray;
+ *   a = albedo[m], or -- texture == MPO_TEXTURE_CHECKER, reading HitRecord.texture_coords (geometry/mod.rs:78-79, interpolated
+ *   at ray_bvh_intersection.rs:80-83; a Sphere's are the origin, primitives.rs:45) -- albedo2[m] on odd cells:
+ *   cell = floor(tex.x * tex_scale) + floor(tex.y * tex_scale), odd iff (cell * 0.5 - floor(cell * 0.5)) != 0 (so NaN counts as odd);
+ *   throughput[c] *= a[c]; at depth == max_depth stop;
  *   next direction = cosine-weighted about n: (x, y) = UnitDisc rejection sample from the SAME Xoshiro stream,
  *   z = sqrt(1 - (x*x + y*y)); orthonormal basis of Duff et al. 2017 (branchless, copysign); origin = point + n * 1e-4.
- * Only + - * / sqrt and comparisons, so the GPU reproduces it bit for bit.  rgba = (L, L, L, primary hit ? 1 : 0).
+ * Only + - * / sqrt floor and comparisons, so the GPU reproduces it bit for bit.  rgba = (L.r, L.g, L.b, primary hit ? 1 : 0).
  * With the defaults this is exactly the round-1 definition (L = 0 + throughput * 1 at the miss, + 0 at every hit). */
 static _Thread_local uint32_t g_max_depth = 0;      /* 0 = reference semantics (worker.rs:51-66) */
 static _Thread_local uint64_t g_segments = 0;
@@ -1455,19 +1461,25 @@ static void render_sample_paths_impl(const mpo_bvh *b, const mpo_sampler *s, uin
     mpo_rng_seed(&rng, mpo_sample_key(seed, width, spp, x, y, sample));
     mpo_ray ray;
     mpo_sample_ray(s, x, y, &rng, &ray);
-    float L = 0.0f, thr = 1.0f, alpha = 0.0f;
+    float L[3] = {0.0f, 0.0f, 0.0f}, thr[3] = {1.0f, 1.0f, 1.0f}, alpha = 0.0f;
     for (uint32_t depth = 1; depth <= max_depth; depth++) {
         mpo_hit h;
         bvh_intersect_impl(b, &ray, st, &h, cnt);
         if (segments) (*segments)++;
-        if (!h.hit) { L = L + thr * b->sky; break; }
+        if (!h.hit) { for (int c = 0; c < 3; c++) L[c] = L[c] + thr[c] * b->sky; break; }
         if (depth == 1) alpha = 1.0f;
         const mpo_material *m = &b->mats[h.material];
-        L = L + thr * m->emission;
+        for (int c = 0; c < 3; c++) L[c] = L[c] + thr[c] * m->emission[c];
         float n[3] = {h.normal[0], h.normal[1], h.normal[2]};
         float dn = ray.d[0] * n[0] + ray.d[1] * n[1] + ray.d[2] * n[2];
         if (dn > 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-        thr = thr * m->albedo;
+        const float *alb = m->albedo;
+        if (m->texture == MPO_TEXTURE_CHECKER) {
+            const float cell = floorf(h.tex[0] * m->tex_scale) + floorf(h.tex[1] * m->tex_scale);
+            const float half = cell * 0.5f;
+            if (half - floorf(half) != 0.0f) alb = m->albedo2;
+        }
+        for (int c = 0; c < 3; c++) thr[c] = thr[c] * alb[c];
         if (depth == max_depth) break;
         float d2[2];
         mpo_rng_unit_disc(&rng, d2);
@@ -1484,7 +1496,7 @@ static void render_sample_paths_impl(const mpo_bvh *b, const mpo_sampler *s, uin
         }
         mpo_ray_new(org, dir, &ray);
     }
-    rgba[0] = rgba[1] = rgba[2] = L;
+    rgba[0] = L[0]; rgba[1] = L[1]; rgba[2] = L[2];
     rgba[3] = alpha;
 }
 

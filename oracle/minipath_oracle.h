@@ -105,7 +105,19 @@ typedef struct {
 typedef struct mpo_bvh mpo_bvh;
 
 /* build-defined path extension: grey diffuse material {albedo, emission}, indexed by TriangleShadingData.material */
-typedef struct { float albedo, emission; } mpo_material;
+/* BUILD-DEFINED material of the path extension (no reference counterpart; see render_sample_paths_impl): diffuse reflectance and
+ * emitted radiance per colour channel; texture = MPO_TEXTURE_CHECKER swaps in albedo2 on the odd cells of a checkerboard over
+ * HitRecord.texture_coords (geometry/mod.rs:78-79), tex_scale cells per unit of texture coordinate. */
+#define MPO_TEXTURE_NONE 0u
+#define MPO_TEXTURE_CHECKER 1u
+typedef struct {
+    float albedo[3];
+    float emission[3];
+    float albedo2[3];
+    uint32_t texture;
+    float tex_scale;
+    uint32_t pad;
+} mpo_material;
 
 /* ---- RNG (R): rand 0.9.3 / rand_distr 0.5.1 ------------------------------------------------------- */
 void mpo_rng_seed(mpo_rng *r, uint64_t state);          /* Xoshiro256PlusPlus::seed_from_u64 (SplitMix64) */

@@ -150,7 +150,7 @@ def lib() -> C.CDLL:
     L.mpo_bvh_from_arrays.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, u32p, f32p, f32p, C.c_uint32,
                                       C.c_uint32, f32p, f32p, C.c_char_p, C.c_size_t]
     L.mpo_bvh_from_arrays.restype = C.c_void_p
-    L.mpo_bvh_set_materials.argtypes = [C.c_void_p, f32p, C.c_uint32, C.c_float]
+    L.mpo_bvh_set_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float]
     L.mpo_bvh_set_materials.restype = C.c_int
     L.mpo_bvh_tri_material.argtypes = [C.c_void_p]
     L.mpo_bvh_tri_material.restype = C.c_void_p
@@ -210,6 +210,29 @@ def lib() -> C.CDLL:
     L.mpo_render_image_paths_mt.restype = C.c_double
     _lib = L
     return L
+
+
+def material_records(table) -> np.ndarray:
+    """mpo_material records (48 B: albedo rgb, emission rgb, albedo2 rgb, texture u32, tex_scale f32, pad) from a table of
+    (albedo, emission) pairs -- scalars = grey, triples = rgb -- or dicts with "albedo", "emission", "albedo2", "checker"."""
+    def rgb(x):
+        a = np.asarray(x, np.float32).reshape(-1)
+        return np.repeat(a, 3) if a.size == 1 else a.reshape(3)
+
+    rec = np.zeros((len(table), 12), np.float32)
+    for i, e in enumerate(table):
+        if isinstance(e, dict):
+            rec[i, 0:3] = rgb(e.get("albedo", 0.75))
+            rec[i, 3:6] = rgb(e.get("emission", 0.0))
+            rec[i, 6:9] = rgb(e.get("albedo2", e.get("albedo", 0.75)))
+            if e.get("checker") is not None:
+                rec[i, 9:10].view(np.uint32)[0] = 1
+                rec[i, 10] = np.float32(e["checker"])
+        else:
+            rec[i, 0:3] = rgb(e[0])
+            rec[i, 3:6] = rgb(e[1])
+            rec[i, 6:9] = rec[i, 0:3]
+    return rec
 
 
 def _f32p(a: np.ndarray):
@@ -333,9 +356,10 @@ class Bvh:
         return cls(h)
 
     def set_materials(self, table, sky: float = 1.0) -> None:
-        """Material table [(albedo, emission), ...] + sky radiance of the build-defined path extension."""
-        t = np.ascontiguousarray(table, np.float32).reshape(-1, 2)
-        if not lib().mpo_bvh_set_materials(self.h, _f32p(t), t.shape[0], C.c_float(sky)):
+        """Material table + sky radiance of the build-defined path extension.  Entries: (albedo, emission) with scalars (grey) or
+        rgb triples, or a dict {"albedo", "emission", "albedo2", "checker": cells per unit of texture coordinate}."""
+        t = material_records(table)
+        if not lib().mpo_bvh_set_materials(self.h, t.ctypes.data_as(C.c_void_p), t.shape[0], C.c_float(sky)):
             raise RuntimeError("material id of a triangle outside the table")
 
     def set_instances(self, translations) -> None:

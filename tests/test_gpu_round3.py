@@ -129,3 +129,80 @@ def test_group_outlives_its_members_handles(ctx):
     assert np.array_equal(bits(after.cpu().numpy()), bits(before))
     assert inst.info().triangle_count == 2256  # info() reads the member's host tree: still there
     inst.close()
+
+
+def test_coloured_and_checker_materials(ctx, oracle):
+    """SURVEY 8 f4 finished: rgb albedo / emission and a checkerboard material that reads
+    HitRecord.texture_coords (geometry/mod.rs:78-79).  Oracle definition: tests/test_golden_cpu.py; here GPU == oracle bit for bit
+    for the fused kernel, the staged pipeline, an object group with a Sphere member (texture coordinates = origin), progressive
+    passes; the chunked rule refuses such tables."""
+    import ctypes as C
+
+    import torch
+
+    pos, nrm, tex, tri = meshes.make("grid_40")
+    mat = (np.arange(tri.shape[0]) % 3).astype(np.uint32)
+    bvh = mp.TriangleBvh.build(pos, nrm, tex, tri, ctx, tri_material=mat)
+    orc = oracle.Bvh.build(pos, nrm, tex, tri, tri_material=mat)
+    table = [{"albedo": (0.9, 0.85, 0.8), "albedo2": (0.1, 0.15, 0.7), "checker": 6.0},
+             ((0.7, 0.2, 0.3), (0.0, 0.0, 0.0)),
+             {"albedo": 0.4, "emission": (1.5, 0.5, 0.0), "albedo2": (0.2, 0.9, 0.2), "checker": 0.75}]
+    eye, at = (0.4, 5.0, 4.5), (0.0, 0.0, 0.0)
+    cam = mp.Camera.default().look_at(eye, at, (0, 1, 0))
+    oc = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(oc))
+    oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(*eye), oracle.vec3(*at), oracle.vec3(0, 1, 0))
+    res, spp, depth, ts = (160, 112), 9, 5, 32
+    smp = oracle.build_sampler(oc, *res)
+    for sky in (0.6, 0.0):
+        bvh.set_materials(table, sky)
+        orc.set_materials(table, sky)
+        of, ou8, _, seg = orc.render_image_paths_mt(smp, res[0], res[1], spp, 21, depth, ts, 8)
+        assert not np.array_equal(of[..., 0], of[..., 2])  # really coloured
+        for wavefront in (False, True):
+            fr = mp.FrameRenderer(mp.Scene(bvh), cam, mp.RenderSettings(ts, spp, res, seed=21, max_depth=depth, wavefront=wavefront))
+            fr.render()
+            img, u8 = fr.untile()
+            torch.cuda.synchronize()
+            assert np.array_equal(bits(img.cpu().numpy()), bits(of)), (sky, wavefront, int(np.sum(bits(img.cpu().numpy()) != bits(of))))
+            assert np.array_equal(u8.cpu().numpy(), ou8) and int(fr.segments.item()) == seg
+            # ragged progressive passes carry {sum r, sum g, sum b, hits}
+            fp = mp.FrameRenderer(mp.Scene(bvh), cam, mp.RenderSettings(ts, spp, res, seed=21, max_depth=depth, wavefront=wavefront))
+            nxt = fp.render_pass(0, 4); nxt = fp.render_pass(nxt, 1); fp.render_pass(nxt)
+            img2, _ = fp.untile()
+            torch.cuda.synchronize()
+            assert np.array_equal(bits(img2.cpu().numpy()), bits(of))
+    with pytest.raises(mp.MinipathError):   # one channel of state per pixel under the chunked rule
+        mp.FrameRenderer(mp.Scene(bvh), cam, mp.RenderSettings(ts, 300, res, seed=21, max_depth=depth, chunked_sum=True)).render()
+    # the reference semantics ignore the table altogether
+    of1, _, _, _, _ = orc.render_image_mt(smp, res[0], res[1], 4, 21, ts, 8)
+    fr = mp.FrameRenderer(mp.Scene(bvh), cam, mp.RenderSettings(ts, 4, res, seed=21))
+    fr.render()
+    img, _ = fr.untile()
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(img.cpu().numpy()), bits(of1))
+    # object group: the grid twice (one turned) and a Sphere; the group's table
+    ball_def = ((0.3, 1.4, 0.2), 0.8)
+    tr = np.array([[0, 0, 0], [0.5, 2.5, -0.5], [0, 0, 0]], np.float32)
+    rot = np.array([[0, 0, 0, 1], [np.sqrt(0.5), 0, 0, np.sqrt(0.5)], [0, 0, 0, 1]], np.float32)
+    grp = mp.ObjectGroup([bvh, bvh, mp.Sphere(*ball_def, ctx)], tr, rotations=rot)
+    grp.set_materials(table, 0.5)
+    orc.set_materials(table, 0.5)
+    orc.set_group([orc, orc, ball_def], tr, rotations=rot)
+    og, _, _, gseg = orc.render_image_paths_mt(smp, res[0], res[1], spp, 5, depth, ts, 8)
+    orc.set_instances(np.zeros((0, 3), np.float32))
+    fr = mp.FrameRenderer(mp.Scene(grp), cam, mp.RenderSettings(ts, spp, res, seed=5, max_depth=depth))
+    fr.render()
+    img, _ = fr.untile()
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(img.cpu().numpy()), bits(og)) and int(fr.segments.item()) == gseg
+    # a grey table on the same scene still takes the one-channel kernels and gives r = g = b
+    bvh.set_materials([(0.5, 0.0), (0.8, 0.1), (0.3, 0.0)], 1.0)
+    orc.set_materials([(0.5, 0.0), (0.8, 0.1), (0.3, 0.0)], 1.0)
+    ogr, _, _, _ = orc.render_image_paths_mt(smp, res[0], res[1], spp, 21, depth, ts, 8)
+    fr = mp.FrameRenderer(mp.Scene(bvh), cam, mp.RenderSettings(ts, spp, res, seed=21, max_depth=depth))
+    fr.render()
+    img, _ = fr.untile()
+    torch.cuda.synchronize()
+    got = img.cpu().numpy()
+    assert np.array_equal(bits(got), bits(ogr)) and np.array_equal(got[..., 0], got[..., 1])

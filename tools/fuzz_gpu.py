@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzzing of the GPU render paths against the oracle: random small scenes, cameras (incl. axis-aligned views that
 produce zero direction components), resolutions, tile sizes, sample counts, kernels (packets / groups / fused paths / staged paths),
-work-unit sizes, progressive splits, material tables and sky radiance, instanced objects and object groups of different meshes, the
+work-unit sizes, progressive splits, material tables (grey, coloured, checker-textured) and sky radiance, instanced objects and object groups of different meshes, the
 chunked accumulation rule.  Every
 frame must match the oracle bit for bit.  usage: fuzz_gpu.py [cases] [seed]"""
 import ctypes as C, os, sys
@@ -53,6 +53,14 @@ def run(cases, seed, ctx=None):
         if chunked:
             spp = int(rng.choice([spp, 300, 513]))
         table = [(float(rng.uniform(0.1, 0.95)), float(rng.choice([0.0, 0.0, 2.5]))) for _ in range(3)]
+        if not chunked and rng.random() < 0.4:   # coloured materials, checkerboards over HitRecord.texture_coords (never with the chunked rule)
+            table = []
+            for _ in range(3):
+                e = {"albedo": [float(x) for x in rng.uniform(0.05, 0.95, 3)], "emission": [float(x) for x in rng.choice([0.0, 0.0, 1.5], 3)]}
+                if rng.random() < 0.5:
+                    e["albedo2"] = [float(x) for x in rng.uniform(0.05, 0.95, 3)]
+                    e["checker"] = float(rng.choice([1.0, 3.0, 7.5, 40.0]))
+                table.append(e)
         sky = float(rng.choice([1.0, 0.0, 0.4]))
         scene.object.set_materials(table, sky); ob.set_materials(table, sky)
         use = scene
