@@ -921,6 +921,46 @@ __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, b
     trace_packet_impl<1, -1>(sc, r, active, st, hit);
 }
 
+// Object group (mp_scene_group / mp_scene_instances) on the packet walk: member by member, in order, the 64 rays are moved into
+// the member's frame (object_ray) and walk the member's own tree as one packet; closest wins with a strict `<`, so the first
+// member keeps ties -- the definition trace_objects (8-lane groups) and the oracle's bvh_intersect_impl implement.  A Sphere
+// member is intersected lane-parallel.  k is wave-uniform: the member's descriptor comes through scalar loads.
+template <class T>
+__device__ __forceinline__ const T* uniform_ptr(const T* p) {  // a wave-uniform pointer that the compiler holds in VGPRs -> SGPRs
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v)), hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return reinterpret_cast<const T*>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+template <bool OCTANTS, class Stack>
+__device__ __forceinline__ void trace_packet_objects(const DevScene& sc, const Ray& r, bool act, Stack& st, PacketHit& h, uint32_t& inst) {
+    h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
+    inst = 0u;
+    for (uint32_t k = 0; k < sc.inst_count; k++) {
+        DevScene sk;
+        Ray rk;
+        object_scene(sc, k, sk);
+        object_ray(sc, k, r, rk);
+        // the packet walk feeds the scalar unit: what it reads through s_load / pushes with v_writelane must sit in SGPRs
+        sk.kind = __builtin_amdgcn_readfirstlane(sk.kind);
+        sk.root = __builtin_amdgcn_readfirstlane(sk.root);
+        sk.root_lit = __builtin_amdgcn_readfirstlane(sk.root_lit);
+        sk.nodes_aos = uniform_ptr(sk.nodes_aos);
+        sk.nodes_lit = uniform_ptr(sk.nodes_lit);
+        sk.tris_aos = uniform_ptr(sk.tris_aos);
+        if (sk.kind == 1u) {  // scene/primitives.rs:16-48 ; prim 0
+            float ts, nn[3];
+            if (act && sphere_intersect(sk, rk, ts, nn) && ts < h.t) { h.t = ts; h.prim = 0u; h.u = h.v = 0.0f; inst = k; }
+            continue;
+        }
+        const bool go = act && may_hit_scene(sk, rk);
+        if (__ballot(go) == 0) continue;
+        PacketHit hk;
+        trace_packet<OCTANTS>(sk, rk, go, st, hk);
+        if (hk.prim != kNoPrim && hk.t < h.t) { h = hk; inst = k; }
+    }
+}
+
 // ---- two rays per lane: 128 rays share one walk (opt-in: mp_ctx_set_option "packet_rays_per_lane" = 2) --------------------
 // The walk's scalar work (record fetches, loop control, pops and pushes) does not depend on how many rays ride on it, and the
 // scalar ALU is the unit the 64-ray walk saturates first (profiles/r02_notes.md).  Here every lane carries TWO rays (A and B: the
@@ -1135,7 +1175,7 @@ __device__ __forceinline__ void add_samples_in_order(float& acc, float c, int la
 // accumulated strictly in sample order (worker.rs:41-43), redundantly by every lane of the pixel (add_samples_in_order).
 // WPE = waves per SIMD the register allocation is held to: 8 (64 VGPRs) hides the scalar-cache misses of scenes that
 // outgrow it, 7 (72 VGPRs) schedules slightly better when the scene stays cache resident (profiles/r01_notes.md).
-template <int S, bool LDS_STACK, int WPE>
+template <int S, bool LDS_STACK, int WPE, bool OBJ = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void render_tiles_packet_kernel(RenderParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : (S <= 32) ? 2 : 1;  // pixel block = BW x BH, BW*BH*S == 64
@@ -1167,24 +1207,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
             Ray r;
             r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
             if (act) sample_ray(P.gen, px, py, s, r);
-            const bool go = act && P.scene.kind == 0u && may_hit_scene(P.scene, r);
             PacketHit h;
             h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
-            if (__ballot(go) != 0) {
-                float* lds = reinterpret_cast<float*>(smem + static_cast<size_t>(static_cast<int>(threadIdx.x) >> 6) * P.lds_per_wave);
+            uint32_t hinst = 0u;
+            float* lds = reinterpret_cast<float*>(smem + static_cast<size_t>(static_cast<int>(threadIdx.x) >> 6) * P.lds_per_wave);
+            if (OBJ) {  // object group: the packet walks every member's tree in turn
                 if (LDS_STACK) {
                     HybridStack st(lds, lane, P.scene.stack_cap, P.scene.packet_stack_regs);
-                    trace_packet<false>(P.scene, r, go, st, h);
+                    trace_packet_objects<false>(P.scene, r, act, st, h, hinst);
                 } else {
                     RegStack st(lds, lane);
-                    trace_packet<(S >= 8 && S <= 32)>(P.scene, r, go, st, h);
+                    trace_packet_objects<(S >= 8 && S <= 32)>(P.scene, r, act, st, h, hinst);
+                }
+            } else {
+                const bool go = act && P.scene.kind == 0u && may_hit_scene(P.scene, r);
+                if (__ballot(go) != 0) {
+                    if (LDS_STACK) {
+                        HybridStack st(lds, lane, P.scene.stack_cap, P.scene.packet_stack_regs);
+                        trace_packet<false>(P.scene, r, go, st, h);
+                    } else {
+                        RegStack st(lds, lane);
+                        trace_packet<(S >= 8 && S <= 32)>(P.scene, r, go, st, h);
+                    }
                 }
             }
             float c = 0.0f;
             bool hit = h.prim != kNoPrim;
             if (hit) {
                 float nn[3];
-                resolve_normal(P.scene, h.prim, h.u, h.v, nn);
+                if (OBJ) object_normal(P.scene, hinst, r, h.prim, h.u, h.v, nn);
+                else resolve_normal(P.scene, h.prim, h.u, h.v, nn);
                 c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60
             } else if (P.scene.kind == 1u) {  // Scene<Sphere>
                 float ts_, nn[3];
@@ -1413,7 +1465,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                 segs += static_cast<unsigned long long>(__popcll(alive_m));
                 h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
                 uint32_t hinst = 0u;
-                if (depth == 1 && !OBJ) {
+                if (depth == 1 && OBJ) {  // camera rays of an object group: one packet walk per member
+                    RegStack rst(nullptr, lane);
+                    HybridStack hst(reinterpret_cast<float*>(stack), lane, P.scene.stack_cap, P.scene.packet_stack_regs);
+                    if (P.scene.stack_cap > P.scene.packet_stack_regs) trace_packet_objects<false>(P.scene, r, alive, hst, h, hinst);
+                    else trace_packet_objects<(S >= 8)>(P.scene, r, alive, rst, h, hinst);
+                } else if (depth == 1) {
                     const bool go = alive && may_hit_scene(P.scene, r);
                     if (__ballot(go) != 0) {
                         RegStack rst(nullptr, lane);
@@ -1422,7 +1479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
                         else trace_packet<(S >= 8)>(P.scene, r, go, rst, h);
                     }
                 } else {
-                    // bounce rays (and every ray of an object group): group walk, once per member
+                    // bounce rays: group walk (once per member of an object group)
                     GroupHit gh;
                     trace_objects<OBJ>(P.scene, r, alive, q, stack, lanes_lt, gh);
                     h.t = gh.t; h.u = gh.u; h.v = gh.v; h.prim = gh.prim;
@@ -1463,6 +1520,7 @@ struct WfState {
     uint32_t* hit_prim;  // n
     float* hit_u;        // n
     float* hit_v;        // n
+    uint32_t* hit_inst;  // n : member of the object group that was hit (groups only; otherwise unused)
     uint32_t* flags;     // n : kWfAlive | kWfPrimaryHit | kWfValid
     uint32_t* key;       // n : sort key of a live path
     uint32_t* idx;       // n : live paths in key order
@@ -1499,7 +1557,7 @@ __device__ __forceinline__ uint32_t direction_bin(float dx, float dy, float dz) 
 
 // path p = (tile_local * ts*ts + (y - min_y) * ts + (x - min_x)) * sc + (s - s0)
 // Stage 1: camera rays, generated and walked as packets of 2x2 pixels x 16 samples like render_tiles_packet_kernel.
-template <bool LDS_STACK>
+template <bool LDS_STACK, bool OBJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void wf_camera_kernel(WfParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int S = 16, BW = 2, BH = 2;
@@ -1531,15 +1589,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             segs += static_cast<unsigned long long>(__popcll(__ballot(act)));
             PacketHit h;
             h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
-            const bool go = act && may_hit_scene(P.scene, r);
-            if (__ballot(go) != 0) {
-                float* lds = reinterpret_cast<float*>(smem + static_cast<size_t>(static_cast<int>(threadIdx.x) >> 6) * P.lds_per_wave);
+            uint32_t hinst = 0u;
+            float* lds = reinterpret_cast<float*>(smem + static_cast<size_t>(static_cast<int>(threadIdx.x) >> 6) * P.lds_per_wave);
+            if (OBJ) {  // object group: one packet walk per member
                 if (LDS_STACK) {
                     HybridStack st(lds, lane, P.scene.stack_cap, P.scene.packet_stack_regs);
-                    trace_packet<false>(P.scene, r, go, st, h);
+                    trace_packet_objects<false>(P.scene, r, act, st, h, hinst);
                 } else {
                     RegStack st(lds, lane);
-                    trace_packet<true>(P.scene, r, go, st, h);
+                    trace_packet_objects<true>(P.scene, r, act, st, h, hinst);
+                }
+            } else {
+                const bool go = act && may_hit_scene(P.scene, r);
+                if (__ballot(go) != 0) {
+                    if (LDS_STACK) {
+                        HybridStack st(lds, lane, P.scene.stack_cap, P.scene.packet_stack_regs);
+                        trace_packet<false>(P.scene, r, go, st, h);
+                    } else {
+                        RegStack st(lds, lane);
+                        trace_packet<true>(P.scene, r, go, st, h);
+                    }
                 }
             }
             if (slot) {
@@ -1556,6 +1625,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
                         P.st.L[c * static_cast<size_t>(n) + p] = 0.0f;
                     }
                     P.st.hit_t[p] = h.t; P.st.hit_prim[p] = h.prim; P.st.hit_u[p] = h.u; P.st.hit_v[p] = h.v;
+                    if (OBJ) P.st.hit_inst[p] = hinst;
                 }
             }
         }
@@ -1564,7 +1634,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
 }
 
 // Stage 2: one thread per path: shade the hit of segment P.depth, draw the bounce ray, count it under its sort key.
-template <int N>
+template <int N, bool OBJ>
 __global__ __launch_bounds__(256) void wf_vertex_kernel(WfParams P) {
     const uint32_t n = P.st.n;
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
@@ -1584,7 +1654,7 @@ __global__ __launch_bounds__(256) void wf_vertex_kernel(WfParams P) {
 #pragma unroll
         for (int c = 0; c < N; c++) { L[c] = P.st.L[c * static_cast<size_t>(n) + p]; thr[c] = P.st.thr[c * static_cast<size_t>(n) + p]; }
         bool primary = (fl & kWfPrimaryHit) != 0u;
-        const bool alive = path_vertex<false, N>(P.scene, h, P.depth, P.max_depth, rng, r, L, thr, primary);
+        const bool alive = path_vertex<OBJ, N>(P.scene, h, P.depth, P.max_depth, rng, r, L, thr, primary, OBJ ? P.st.hit_inst[p] : 0u);
         fl = (fl & ~(kWfAlive | kWfPrimaryHit)) | (alive ? kWfAlive : 0u) | (primary ? kWfPrimaryHit : 0u);
         P.st.flags[p] = fl;
 #pragma unroll
@@ -1645,6 +1715,7 @@ __global__ __launch_bounds__(256) void wf_scatter_kernel(WfParams P) {
 // Stage 5: the sorted rays through the 8-lane-group traversal, 64 per wave.  (Walking 64 sorted rays as ONE packet was measured
 // too: diffuse bounce rays do not share enough of the tree even when sorted -- 2 586 VALU per ray against ~500 here; see
 // profiles/r01_notes.md.)  The sort serves cache locality.
+template <bool OBJ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void wf_trace_groups_kernel(WfParams P) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
@@ -1666,22 +1737,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             r.iy = (r.dy == 0.0f) ? INFINITY : 1.0f / r.dy;
             r.iz = (r.dz == 0.0f) ? INFINITY : 1.0f / r.dz;
         }
-        const bool go = act && may_hit_scene(P.scene, r);
-        const uint64_t gm = __ballot(go);
-        const int cnt = __popcll(gm), rank = __popcll(gm & ((1ull << lane) - 1ull));
-        if (go) {
-            q[0 * 64 + rank] = r.ox; q[1 * 64 + rank] = r.oy; q[2 * 64 + rank] = r.oz;
-            q[3 * 64 + rank] = r.dx; q[4 * 64 + rank] = r.dy; q[5 * 64 + rank] = r.dz;
-        }
-        wave_lds_sync();
-        trace_wave(P.scene, q, stack, cnt);
+        // compaction of the rays that can reach the object into the wave's queue + the 8-lane-group walk (once per member of an
+        // object group, closest wins)
+        GroupHit gh;
+        trace_objects<OBJ>(P.scene, r, act, q, stack, (1ull << lane) - 1ull, gh);
         if (act) {
-            P.st.hit_t[p] = go ? q[0 * 64 + rank] : FLT_MAX;
-            P.st.hit_prim[p] = go ? as_u(q[1 * 64 + rank]) : kNoPrim;
-            P.st.hit_u[p] = go ? q[2 * 64 + rank] : 0.0f;
-            P.st.hit_v[p] = go ? q[3 * 64 + rank] : 0.0f;
+            P.st.hit_t[p] = gh.t;
+            P.st.hit_prim[p] = gh.prim;
+            P.st.hit_u[p] = gh.u;
+            P.st.hit_v[p] = gh.v;
+            if (OBJ) P.st.hit_inst[p] = gh.inst;
         }
-        wave_lds_sync();
     }
 }
 
@@ -1982,7 +2048,7 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
 #undef MP_LAUNCH_PATHS
         return check(hipGetLastError(), "render_paths_kernel launch", err);
     }
-    if (L.traversal == 1 || L.scene.inst_count != 0u) {  // object groups are walked member by member by the 8-lane groups
+    if (L.traversal == 1) {  // MP_FLAG_TRAVERSAL_GROUPS
         const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want, static_cast<uint64_t>(L.cu_count) * 8));
         if (L.scene.inst_count != 0u) hipLaunchKernelGGL((render_tiles_kernel<1, true>), dim3(grid), dim3(256), lds, st, P);
         else hipLaunchKernelGGL((render_tiles_kernel<1, false>), dim3(grid), dim3(256), lds, st, P);
@@ -1995,12 +2061,14 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     // small launches (a rank's shard of a multi-GPU frame): 2-pixel units, so that the tail of the launch is half as long
     if (nspp >= 32 && units * 16u < static_cast<uint64_t>(L.cu_count) * 32u * 24u) S = 32;
     if (L.packet_samples) S = static_cast<int>(std::min<uint32_t>(L.packet_samples, 64u));
+    const bool obj = L.scene.inst_count != 0u;  // object group: one packet walk per member (instantiated for 16 and 1 samples in flight)
+    if (obj) S = (S >= 16 && nspp >= 16) ? 16 : 1;
     const bool lds_stack = L.scene.stack_cap > L.scene.packet_stack_regs;
     P.lds_per_wave = lds_stack ? (L.scene.stack_cap - L.scene.packet_stack_regs) * 16u : 0u;  // one uint4 per entry beyond the register stack
     const uint32_t plds = P.lds_per_wave * 4;
     if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
     const uint32_t per_cu = plds ? std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds)) : 8u;
-    if (S == 16 && L.rays_per_lane == 2 && !lds_stack && L.scene.kind == 0u && L.scene.stack_cap <= 64u) {
+    if (S == 16 && L.rays_per_lane == 2 && !lds_stack && !obj && L.scene.kind == 0u && L.scene.stack_cap <= 64u) {
         // 128-ray walks: two rays per lane (8-pixel units)
         const uint64_t units2 = static_cast<uint64_t>(L.n_tiles) * ((L.tile_size + 3) / 4) * ((L.tile_size + 1) / 2);
         const uint32_t grid2 = static_cast<uint32_t>(std::min<uint64_t>((units2 + 3) / 4, static_cast<uint64_t>(L.cu_count) * 8));
@@ -2015,7 +2083,12 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         if (lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<SV, true, W>), dim3(grid), dim3(256), plds, st, P); \
         else hipLaunchKernelGGL((render_tiles_packet_kernel<SV, false, W>), dim3(grid), dim3(256), 0, st, P);           \
     } while (0)
-    if (S == 64) MP_LAUNCH_PACKET(64, 7);
+    if (obj) {
+        if (S == 16 && lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<16, true, 7, true>), dim3(grid), dim3(256), plds, st, P);
+        else if (S == 16) hipLaunchKernelGGL((render_tiles_packet_kernel<16, false, 7, true>), dim3(grid), dim3(256), 0, st, P);
+        else if (lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<1, true, 7, true>), dim3(grid), dim3(256), plds, st, P);
+        else hipLaunchKernelGGL((render_tiles_packet_kernel<1, false, 7, true>), dim3(grid), dim3(256), 0, st, P);
+    } else if (S == 64) MP_LAUNCH_PACKET(64, 7);
     else if (S == 32 && big) MP_LAUNCH_PACKET(32, 8);
     else if (S == 32) MP_LAUNCH_PACKET(32, 7);
     else if (S == 16 && big) MP_LAUNCH_PACKET(16, 8);
@@ -2031,7 +2104,8 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
 int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::string& err) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (L.n_tiles == 0) return MP_OK;
-    if (L.scene.kind != 0u || L.max_depth == 0 || L.scene.inst_count != 0u) { err = "the staged path evaluation needs MP_FLAG_PATHS and a plain TriangleBvh scene"; return MP_ERR_UNSUPPORTED; }
+    if (L.scene.kind != 0u || L.max_depth == 0) { err = "the staged path evaluation needs MP_FLAG_PATHS and a TriangleBvh scene or an object group"; return MP_ERR_UNSUPPORTED; }
+    const bool obj = L.scene.inst_count != 0u;
     WfParams P;
     P.scene = L.scene;
     P.gen.s = L.sampler;
@@ -2063,7 +2137,7 @@ int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::stri
     if (nchan == 3u && L.chunked) { err = "coloured / textured materials are not combined with MP_FLAG_CHUNKED_SUM"; return MP_ERR_UNSUPPORTED; }
     P.st.nchan = nchan;
     const size_t n64 = (static_cast<size_t>(n_max) + 63) & ~static_cast<size_t>(63);
-    const size_t bytes = n64 * (84 + 8 * nchan) + (static_cast<size_t>(nbins) + 64) * 4 * 3;
+    const size_t bytes = n64 * (88 + 8 * nchan) + (static_cast<size_t>(nbins) + 64) * 4 * 3;
     unsigned char* ws = nullptr;
     int rc = check(hipMallocAsync(reinterpret_cast<void**>(&ws), bytes, st), "hipMallocAsync(path state)", err);
     if (rc) return rc;
@@ -2077,6 +2151,7 @@ int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::stri
     P.st.hit_prim = reinterpret_cast<uint32_t*>(take(n64 * 4));
     P.st.hit_u = reinterpret_cast<float*>(take(n64 * 4));
     P.st.hit_v = reinterpret_cast<float*>(take(n64 * 4));
+    P.st.hit_inst = reinterpret_cast<uint32_t*>(take(n64 * 4));
     P.st.flags = reinterpret_cast<uint32_t*>(take(n64 * 4));
     P.st.key = reinterpret_cast<uint32_t*>(take(n64 * 4));
     P.st.idx = reinterpret_cast<uint32_t*>(take(n64 * 4));
@@ -2104,8 +2179,10 @@ int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::stri
             if (rc) break;
             const uint32_t units = ntb * ((ts + 1) / 2) * ((ts + 1) / 2);
             const uint32_t cam_grid = std::min<uint32_t>((units + 3) / 4, cus * per_cu);
-            if (lds_stack) hipLaunchKernelGGL(wf_camera_kernel<true>, dim3(cam_grid), dim3(256), plds, st, P);
-            else hipLaunchKernelGGL(wf_camera_kernel<false>, dim3(cam_grid), dim3(256), 0, st, P);
+            if (obj && lds_stack) hipLaunchKernelGGL((wf_camera_kernel<true, true>), dim3(cam_grid), dim3(256), plds, st, P);
+            else if (obj) hipLaunchKernelGGL((wf_camera_kernel<false, true>), dim3(cam_grid), dim3(256), 0, st, P);
+            else if (lds_stack) hipLaunchKernelGGL((wf_camera_kernel<true, false>), dim3(cam_grid), dim3(256), plds, st, P);
+            else hipLaunchKernelGGL((wf_camera_kernel<false, false>), dim3(cam_grid), dim3(256), 0, st, P);
             const uint32_t flat_grid = std::min<uint32_t>((P.st.n + 255u) / 256u, cus * 16u);
             WfParams G = P;  // bounce stage: LDS ray queue + eight traversal stacks per wave
             G.lds_per_wave = lds_bytes_per_wave(L.scene.stack_cap);
@@ -2114,12 +2191,15 @@ int launch_render_paths_wavefront(const RenderLaunch& L, void* stream, std::stri
             const uint32_t gper = std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / glds));
             for (uint32_t depth = 1; depth <= L.max_depth; depth++) {
                 P.depth = depth;
-                if (nchan == 3u) hipLaunchKernelGGL(wf_vertex_kernel<3>, dim3(flat_grid), dim3(256), 0, st, P);
-                else hipLaunchKernelGGL(wf_vertex_kernel<1>, dim3(flat_grid), dim3(256), 0, st, P);
+                if (nchan == 3u && obj) hipLaunchKernelGGL((wf_vertex_kernel<3, true>), dim3(flat_grid), dim3(256), 0, st, P);
+                else if (nchan == 3u) hipLaunchKernelGGL((wf_vertex_kernel<3, false>), dim3(flat_grid), dim3(256), 0, st, P);
+                else if (obj) hipLaunchKernelGGL((wf_vertex_kernel<1, true>), dim3(flat_grid), dim3(256), 0, st, P);
+                else hipLaunchKernelGGL((wf_vertex_kernel<1, false>), dim3(flat_grid), dim3(256), 0, st, P);
                 if (depth == L.max_depth) break;
                 hipLaunchKernelGGL(wf_scan_kernel, dim3(1), dim3(1024), 0, st, P);
                 hipLaunchKernelGGL(wf_scatter_kernel, dim3(flat_grid), dim3(256), 0, st, P);
-                hipLaunchKernelGGL(wf_trace_groups_kernel, dim3(cus * gper), dim3(256), glds, st, G);
+                if (obj) hipLaunchKernelGGL(wf_trace_groups_kernel<true>, dim3(cus * gper), dim3(256), glds, st, G);
+                else hipLaunchKernelGGL(wf_trace_groups_kernel<false>, dim3(cus * gper), dim3(256), glds, st, G);
             }
             const uint32_t px_grid = std::min<uint32_t>((ntb * ts * ts + 255u) / 256u, cus * 16u);
             hipLaunchKernelGGL(wf_accumulate_kernel, dim3(px_grid), dim3(256), 0, st, P);

@@ -331,8 +331,8 @@ def test_instanced_object(ctx, oracle, teapot_oracle_bvh):
     pf, _, _, pseg = orc.render_image_paths_mt(osmp, res[0], res[1], 4, 3, 5, 32, 8)
     b, gseg = _render(scene, cam, mp.RenderSettings(32, 4, res, seed=3, max_depth=5))
     assert np.array_equal(bits(b), bits(pf)) and gseg == pseg
-    with pytest.raises(mp.MinipathError):
-        _render(scene, cam, mp.RenderSettings(32, 4, res, seed=3, max_depth=5, wavefront=True))
+    w, wseg = _render(scene, cam, mp.RenderSettings(32, 4, res, seed=3, max_depth=5, wavefront=True))  # round 3: the staged pipeline takes groups
+    assert np.array_equal(bits(w), bits(pf)) and wseg == pseg
     with pytest.raises(mp.MinipathError):
         mp.Instances(inst, tr)  # instances of instances are not defined
     # one identity instance == the plain object
@@ -421,6 +421,13 @@ def test_object_group_of_different_meshes(ctx, oracle):
         pf, _, _, pseg = box.render_image_paths_mt(osmp, res[0], res[1], spp, 5, 6, 32, 8)
         b, gseg = _render(scene, cam, mp.RenderSettings(32, spp, res, seed=5, max_depth=6))
         assert np.array_equal(bits(b), bits(pf)) and gseg == pseg, spp
+        w, wseg = _render(scene, cam, mp.RenderSettings(32, spp, res, seed=5, max_depth=6, wavefront=True))  # round 3: staged pipeline on groups
+        assert np.array_equal(bits(w), bits(pf)) and wseg == pseg, ("staged", spp)
+    # 17 spp at 16 samples in flight and 3 spp one sample per lane: both instantiations of the group packet kernel (round 3)
+    for spp in (17, 3):
+        of2, _, _, _, _ = box.render_image_mt(osmp, res[0], res[1], spp, 5, 32, 8)
+        a2, _ = _render(scene, cam, mp.RenderSettings(32, spp, res, seed=5))
+        assert np.array_equal(bits(a2), bits(of2)), spp
     # chunked sums over split passes
     st = mp.RenderSettings(32, 600, (64, 40), seed=5, max_depth=3, chunked_sum=True)
     fr = mp.FrameRenderer(scene, mp.Camera.default().look_at(eye, at, (0, 1, 0)), st)
@@ -441,8 +448,6 @@ def test_object_group_of_different_meshes(ctx, oracle):
         mp.ObjectGroup([group, teapot], [[0, 0, 0], [1, 0, 0]])       # groups do not nest
     with pytest.raises(mp.MinipathError):
         group.export()                                                # a group has no arrays of its own
-    with pytest.raises(mp.MinipathError):
-        _render(scene, cam, mp.RenderSettings(32, 4, res, seed=3, max_depth=5, wavefront=True))
     # a one-member group at the origin == the member itself
     one = mp.Scene(mp.ObjectGroup([gpu[1]], [[0, 0, 0]]))
     vcam = mp.Camera.default().look_at((0, 0, 9), (0, 0, 0), (0, 1, 0))

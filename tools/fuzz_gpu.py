@@ -65,10 +65,10 @@ def run(cases, seed, ctx=None):
         scene.object.set_materials(table, sky); ob.set_materials(table, sky)
         use = scene
         pick = rng.random()
-        if mode != "staged" and pick < 0.15:   # instanced object: 2-4 translated copies
+        if pick < 0.15:   # instanced object: 2-4 translated copies
             tr = (rng.normal(size=(int(rng.integers(2, 5)), 3)) * 3.0).astype(np.float32)
             use = mp.Scene(mp.Instances(scene.object, tr)); ob.set_instances(tr)
-        elif mode != "staged" and pick < 0.3:   # object group: 2-4 members drawn from all the scenes (this one is the container)
+        elif pick < 0.3:   # object group: 2-4 members drawn from all the scenes (this one is the container)
             names = [name] + [list(scenes)[int(rng.integers(len(scenes)))] for _ in range(int(rng.integers(1, 4)))]
             order = rng.permutation(len(names))
             names = [names[i] for i in order]
