@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Cost of splitting a frame's samples over progressive passes (MP_FLAG_ACCUMULATE): teapot 1080p x256 in 1, 4, 16 passes."""
+"""Cost of splitting a frame's samples over progressive passes (MP_FLAG_ACCUMULATE): teapot 1080p x256 in 1, 4, 16 passes;
+`progressive_cost.py single`: the time of ONE pass of k = 1..64 samples per pixel."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +10,14 @@ scene = mp.Scene(mp.TriangleBvh.with_obj(os.path.join(os.path.dirname(__file__),
 st = mp.RenderSettings(64, 256, (1920, 1080), seed=0x5EED)
 fr = mp.FrameRenderer(scene, mp.Camera.teapot_view(), st)
 fr.render(); torch.cuda.synchronize(); fr.rebalance()
+if len(sys.argv) > 1 and sys.argv[1] == "single":   # time of ONE progressive pass of k samples per pixel (sample_count 256)
+    for k in (1, 2, 4, 8, 16, 32, 64):
+        fr.render_pass(0, k); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(5): fr.render_pass(k, k)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+        print(f"pass of {k:2d} spp: {dt*1e3:.3f} ms = {1920*1080*k/dt/1e9:.1f} Grays/s")
+    sys.exit(0)
 ref = None
 for passes in (1, 4, 16):
     per = 256 // passes

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Would sorting incoherent (bounce) rays into 64-ray packets pay?  Bounce-like rays leaving the atrium's surfaces are keyed by
 (origin grid cell, direction bin), sorted, cut into packets of 64; for each packet the union of inner nodes / leaf packets its rays
-visit (what the packet walk would pay) is compared with the per-ray average (what a single ray needs).  Diagnostics only."""
+visit (what the packet walk would pay) is compared with the per-ray average (what a single ray needs).
+`sim_sorted_packets.py window ...`: the same for bounce rays that start inside one screen window.  Diagnostics only."""
 import ctypes as C, sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -52,4 +53,48 @@ def main():
             un += len(nodes); up += sum(leaves.values()); cnt += 1
         print(f"cells {cells}^3 x dir bins {8*dbins*dbins}: union per 64-ray packet {un/cnt:.1f} nodes ({un/cnt/per_nodes:.1f}x), {up/cnt:.1f} packets ({up/cnt/per_pk:.1f}x)")
 
-main()
+def main_window():
+    """`sim_sorted_packets.py window [detail] [win] [spp]`: direction-sorting bounce rays that start inside one screen window (nearby
+    origins): union of visited nodes / packets per 64-ray packet vs the per-ray average."""
+    sys.argv.pop(1)
+    detail = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
+    win = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    spp = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    b = po.Bvh.build(*scenes.atrium(1, detail))
+    cam = po.Camera(); po.lib().mpo_camera_default(C.byref(cam)); po.lib().mpo_camera_look_at(C.byref(cam), po.vec3(-16.0, 4.2, 0.8), po.vec3(12.0, 5.5, -0.5), po.vec3(0, 1, 0)); cam.f_number = 4.0
+    s = po.build_sampler(cam, 1920, 1080)
+    L = po.lib(); rng = np.random.default_rng(5)
+    for (x0, y0) in ((900, 500), (300, 800), (1500, 300)):
+        o, d = [], []
+        for y in range(y0, y0 + win):
+            for x in range(x0, x0 + win):
+                for smp in range(spp):
+                    r = po.sample_ray(s, x, y, L.mpo_sample_key(1, 1920, spp, x, y, smp))
+                    o.append([r.o[0], r.o[1], r.o[2]]); d.append([r.d[0], r.d[1], r.d[2]])
+        o = np.array(o, np.float32); d = np.array(d, np.float32)
+        t, prim, u, v = b.trace(o, d)
+        hit = prim != 0xFFFFFFFF
+        o2 = (o + d * t[:, None])[hit]
+        d2 = rng.normal(size=o2.shape).astype(np.float32); d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+        o2 = (o2 + 1e-3 * d2).astype(np.float32)
+        vis = visits(b, o2, d2)
+        per_nodes = np.mean([len(a) for a, _ in vis]); per_pk = np.mean([sum(k for _, k in l) for _, l in vis])
+        print(f"window ({x0},{y0}) {win}x{win}x{spp}: {o2.shape[0]} bounce rays, per ray {per_nodes:.1f} nodes {per_pk:.1f} packets")
+        for dbins in (0, 1, 2, 4, 8, 16):
+            if dbins == 0:
+                order = np.arange(o2.shape[0])
+            else:
+                a = np.abs(d2); q = np.clip((a / a.sum(axis=1, keepdims=True) * dbins).astype(np.int64), 0, dbins - 1)
+                key = ((d2[:, 0] < 0) * 4 + (d2[:, 1] < 0) * 2 + (d2[:, 2] < 0)).astype(np.int64) * dbins * dbins + q[:, 0] * dbins + q[:, 1]
+                order = np.argsort(key, kind="stable")
+            un = up = cnt = 0
+            for st in range(0, len(order) - 63, 64):
+                nodes = set(); leaves = {}
+                for i in order[st:st + 64]:
+                    nodes.update(vis[i][0])
+                    for l, k in vis[i][1]: leaves[l] = k
+                un += len(nodes); up += sum(leaves.values()); cnt += 1
+            print(f"   dir bins {8*dbins*dbins:5d}: union per packet {un/cnt:.1f} nodes ({un/cnt/per_nodes:.1f}x) {up/cnt:.1f} packets ({up/cnt/per_pk:.1f}x)")
+
+if __name__ == "__main__":
+    main_window() if len(sys.argv) > 1 and sys.argv[1] == "window" else main()
