@@ -551,6 +551,21 @@ __device__ __forceinline__ void pixel_state_store(const RenderParams& P, size_t 
     *reinterpret_cast<float4*>(P.out + off) = make_float4(m, m, m, a);
 }
 
+// The render kernels take RenderParams by value (328 bytes of kernel arguments) but read it through the kernarg segment pointer,
+// one short-lived VIEW per phase (unit setup, ray generation, walk, shading, accumulation): a compiler barrier on the pointer
+// ends the life of everything loaded through the previous view, so a field costs an s_load from the constant cache where it is
+// used instead of an SGPR for the whole kernel -- the walks need the scalar registers for their record double-buffers, and what
+// did not fit was spilled to VGPR lanes and scratch (round 2: 78 SGPR + 4 VGPR spills in the packet kernel, 67 + 29 and 104 B of
+// scratch in the path kernel).
+typedef const __attribute__((address_space(4))) RenderParams* kparams_t;
+template <class T>
+__device__ __forceinline__ const T& kernarg_view(const __attribute__((address_space(4))) T* kp) {
+    asm volatile("" : "+s"(kp));
+    return *(const T*)kp;
+}
+__device__ __forceinline__ const RenderParams& params_view(kparams_t kp) { return kernarg_view<RenderParams>(kp); }
+#define MP_KERNEL_PARAMS kparams_t KP = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr()
+
 // get_next_tile (machinery.rs:206-208) for wavefronts: kWorkQueues interleaved queues (mp_internal.h), home queue = this
 // workgroup's XCD, the others once it is empty.  Wave-uniform; `state` = queue | consecutive dry queues << 8 (one SGPR: the
 // packet kernel has none to spare).  Used as:  for (;;) { MP_NEXT_UNIT(unit); ... }
@@ -572,21 +587,24 @@ __device__ __forceinline__ void pixel_state_store(const RenderParams& P, size_t 
 
 // S = samples of one pixel in flight in a wavefront (64/S pixels x S consecutive samples per pass).
 template <int S, bool OBJ>
-__global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams P) {
+__global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams) {
     extern __shared__ __align__(16) unsigned char smem[];
+    MP_KERNEL_PARAMS;
+    const RenderParams& P0 = params_view(KP);
     constexpr int BW = (S == 1) ? 8 : (S == 2) ? 8 : (S == 4) ? 4 : 4;
     constexpr int BH = 64 / S / BW;
     const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
-    float* q = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P.lds_per_wave);
+    float* q = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P0.lds_per_wave);
     uint2* stack = reinterpret_cast<uint2*>(q + kQueueFloats);
-    const uint32_t ts = P.tile_size;
+    const uint32_t ts = P0.tile_size;
     const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by;
-    const uint32_t total = P.n_tiles * upt;
+    const uint32_t total = P0.n_tiles * upt;
     const uint64_t lanes_lt = (1ull << lane) - 1ull;
     const int pix = lane / S, sub = lane % S;
 
     uint32_t qstate = blockIdx.x % kWorkQueues;
     for (;;) {
+        const RenderParams& P = params_view(KP);  // one view per work unit
         MP_NEXT_UNIT(unit)
         const uint32_t b = unit % upt;
         const uint32_t tile_i = P.tile_order ? P.tile_order[unit / upt] : unit / upt;
@@ -1176,17 +1194,19 @@ __device__ __forceinline__ void add_samples_in_order(float& acc, float c, int la
 // WPE = waves per SIMD the register allocation is held to: 8 (64 VGPRs) hides the scalar-cache misses of scenes that
 // outgrow it, 7 (72 VGPRs) schedules slightly better when the scene stays cache resident (profiles/r01_notes.md).
 template <int S, bool LDS_STACK, int WPE, bool OBJ = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void render_tiles_packet_kernel(RenderParams P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void render_tiles_packet_kernel(RenderParams) {
     extern __shared__ __align__(16) unsigned char smem[];
+    MP_KERNEL_PARAMS;
     constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : (S <= 32) ? 2 : 1;  // pixel block = BW x BH, BW*BH*S == 64
     constexpr int BH = 64 / S / BW;
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const int pix = lane / S, sub = lane % S;
     const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1));
-    const uint32_t ts = P.tile_size;
-    const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
     uint32_t qstate = blockIdx.x % kWorkQueues;
     for (;;) {
+        const RenderParams& P = params_view(KP);  // unit setup
+        const uint32_t ts = P.tile_size;
+        const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
         MP_NEXT_UNIT(unit)
         const uint32_t b = unit % upt;
         const uint32_t tile_i = P.tile_order ? P.tile_order[unit / upt] : unit / upt;
@@ -1201,55 +1221,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
         pixel_state_load(P, off, inpix, sub == 0, acc, cnt);
         // passes are aligned to multiples of S in the absolute sample index, so that a chunk boundary (MP_FLAG_CHUNKED_SUM) never
         // falls inside a pass; lanes outside [s_begin, s_end) add +0.0, which is exact
-        for (uint32_t s0 = P.s_begin & ~static_cast<uint32_t>(S - 1); s0 < P.s_end; s0 += S) {
+        const uint32_t s_begin = P.s_begin, s_end = P.s_end;
+        for (uint32_t s0 = s_begin & ~static_cast<uint32_t>(S - 1); s0 < s_end; s0 += S) {
             const uint32_t s = s0 + static_cast<uint32_t>(sub);
-            const bool act = inpix && s >= P.s_begin && s < P.s_end;
+            const bool act = inpix && s >= s_begin && s < s_end;
             Ray r;
             r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
-            if (act) sample_ray(P.gen, px, py, s, r);
+            {
+                const RenderParams& G = params_view(KP);  // ray generation
+                if (act) sample_ray(G.gen, px, py, s, r);
+            }
             PacketHit h;
             h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
             uint32_t hinst = 0u;
-            float* lds = reinterpret_cast<float*>(smem + static_cast<size_t>(static_cast<int>(threadIdx.x) >> 6) * P.lds_per_wave);
-            if (OBJ) {  // object group: the packet walks every member's tree in turn
-                if (LDS_STACK) {
-                    HybridStack st(lds, lane, P.scene.stack_cap, P.scene.packet_stack_regs);
-                    trace_packet_objects<false>(P.scene, r, act, st, h, hinst);
-                } else {
-                    RegStack st(lds, lane);
-                    trace_packet_objects<(S >= 8 && S <= 32)>(P.scene, r, act, st, h, hinst);
-                }
-            } else {
-                const bool go = act && P.scene.kind == 0u && may_hit_scene(P.scene, r);
-                if (__ballot(go) != 0) {
+            {
+                const RenderParams& W = params_view(KP);  // walk
+                float* lds = reinterpret_cast<float*>(smem + static_cast<size_t>(static_cast<int>(threadIdx.x) >> 6) * W.lds_per_wave);
+                if (OBJ) {  // object group: the packet walks every member's tree in turn
                     if (LDS_STACK) {
-                        HybridStack st(lds, lane, P.scene.stack_cap, P.scene.packet_stack_regs);
-                        trace_packet<false>(P.scene, r, go, st, h);
+                        HybridStack st(lds, lane, W.scene.stack_cap, W.scene.packet_stack_regs);
+                        trace_packet_objects<false>(W.scene, r, act, st, h, hinst);
                     } else {
                         RegStack st(lds, lane);
-                        trace_packet<(S >= 8 && S <= 32)>(P.scene, r, go, st, h);
+                        trace_packet_objects<(S >= 8 && S <= 32)>(W.scene, r, act, st, h, hinst);
+                    }
+                } else {
+                    const bool go = act && W.scene.kind == 0u && may_hit_scene(W.scene, r);
+                    if (__ballot(go) != 0) {
+                        if (LDS_STACK) {
+                            HybridStack st(lds, lane, W.scene.stack_cap, W.scene.packet_stack_regs);
+                            trace_packet<false>(W.scene, r, go, st, h);
+                        } else {
+                            RegStack st(lds, lane);
+                            trace_packet<(S >= 8 && S <= 32)>(W.scene, r, go, st, h);
+                        }
                     }
                 }
             }
             float c = 0.0f;
             bool hit = h.prim != kNoPrim;
+            const RenderParams& H = params_view(KP);  // shading + accumulation
             if (hit) {
                 float nn[3];
-                if (OBJ) object_normal(P.scene, hinst, r, h.prim, h.u, h.v, nn);
-                else resolve_normal(P.scene, h.prim, h.u, h.v, nn);
+                if (OBJ) object_normal(H.scene, hinst, r, h.prim, h.u, h.v, nn);
+                else resolve_normal(H.scene, h.prim, h.u, h.v, nn);
                 c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60
-            } else if (P.scene.kind == 1u) {  // Scene<Sphere>
+            } else if (H.scene.kind == 1u) {  // Scene<Sphere>
                 float ts_, nn[3];
-                hit = act && sphere_intersect(P.scene, r, ts_, nn);
+                hit = act && sphere_intersect(H.scene, r, ts_, nn);
                 if (hit) c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);
             }
             // alpha sums 1.0 per hit: an exact integer in f32, so the order is irrelevant
             cnt += static_cast<float>(__popcll(__ballot(hit) & pixel_lanes));
             add_samples_in_order<S>(acc, c, lane);  // misses add +0.0 (exact)
-            if (P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) chunk_flush(P, off, inpix && sub == 0, acc);
+            if (H.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= s_end) chunk_flush(H, off, inpix && sub == 0, acc);
         }
-        if (inpix && sub == 0) pixel_state_store(P, off, acc, cnt);
-        if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
+        const RenderParams& E = params_view(KP);  // unit end
+        if (inpix && sub == 0) pixel_state_store(E, off, acc, cnt);
+        if (E.tile_cost && lane == 0) atomicAdd(E.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
     }
 }
 
@@ -1411,23 +1440,26 @@ __device__ __forceinline__ void pixel_state_store3(const RenderParams& P, size_t
     *reinterpret_cast<float4*>(P.out + off) = make_float4(acc[0] * s, acc[1] * s, acc[2] * s, cnt * s);
 }
 
+#ifndef MP_PATHS_WPE
+#define MP_PATHS_WPE 6  // waves per SIMD the path kernel's registers are held to (A/B-measured, profiles/r03_notes.md)
+#endif
 template <int S, bool OBJ, bool RGB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) void render_paths_kernel(RenderParams P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_PATHS_WPE, 8))) void render_paths_kernel(RenderParams) {
     constexpr int N = RGB ? 3 : 1;
     extern __shared__ __align__(16) unsigned char smem[];
+    MP_KERNEL_PARAMS;  // RenderParams through short-lived views (params_view)
     constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : 2;
     constexpr int BH = 64 / S / BW;
     const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
-    float* q = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P.lds_per_wave);
-    uint2* stack = reinterpret_cast<uint2*>(q + kQueueFloats);
     const int pix = lane / S, sub = lane % S;
     const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1));
     const uint64_t lanes_lt = (1ull << lane) - 1ull;
-    const uint32_t ts = P.tile_size;
-    const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
     unsigned long long segs = 0;  // wave-uniform
     uint32_t qstate = blockIdx.x % kWorkQueues;
     for (;;) {
+        const RenderParams& P = params_view(KP);  // unit setup
+        const uint32_t ts = P.tile_size;
+        const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
         MP_NEXT_UNIT(unit)
         const uint32_t b = unit % upt;
         const uint32_t tile_i = P.tile_order ? P.tile_order[unit / upt] : unit / upt;
@@ -1443,62 +1475,75 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8))) voi
         else pixel_state_load(P, off, inpix, sub == 0, acc[0], cnt);
         // passes are aligned to multiples of S in the absolute sample index, so that a chunk boundary (MP_FLAG_CHUNKED_SUM) never
         // falls inside a pass; lanes outside [s_begin, s_end) add +0.0, which is exact
-        for (uint32_t s0 = P.s_begin & ~static_cast<uint32_t>(S - 1); s0 < P.s_end; s0 += S) {
+        const uint32_t s_begin = P.s_begin, s_end = P.s_end, max_depth = P.max_depth;
+        for (uint32_t s0 = s_begin & ~static_cast<uint32_t>(S - 1); s0 < s_end; s0 += S) {
             const uint32_t s = s0 + static_cast<uint32_t>(sub);
-            const bool act = inpix && s >= P.s_begin && s < P.s_end;
+            const bool act = inpix && s >= s_begin && s < s_end;
             Rng rng;
             rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
             Ray r;
             r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
-            if (act) {
-                rng_seed(rng, sample_key(P.gen, px, py, s));
-                sample_ray_rng(P.gen, px, py, rng, r);
+            {
+                const RenderParams& G = params_view(KP);  // ray generation
+                if (act) {
+                    rng_seed(rng, sample_key(G.gen, px, py, s));
+                    sample_ray_rng(G.gen, px, py, rng, r);
+                }
             }
             float L[N], thr[N];
 #pragma unroll
             for (int c = 0; c < N; c++) { L[c] = 0.0f; thr[c] = 1.0f; }
             bool alive = act, primary_hit = false;
             PacketHit h;
-            for (uint32_t depth = 1; depth <= P.max_depth; depth++) {
+            for (uint32_t depth = 1; depth <= max_depth; depth++) {
                 const uint64_t alive_m = __ballot(alive);
                 if (alive_m == 0) break;
                 segs += static_cast<unsigned long long>(__popcll(alive_m));
                 h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
                 uint32_t hinst = 0u;
-                if (depth == 1 && OBJ) {  // camera rays of an object group: one packet walk per member
-                    RegStack rst(nullptr, lane);
-                    HybridStack hst(reinterpret_cast<float*>(stack), lane, P.scene.stack_cap, P.scene.packet_stack_regs);
-                    if (P.scene.stack_cap > P.scene.packet_stack_regs) trace_packet_objects<false>(P.scene, r, alive, hst, h, hinst);
-                    else trace_packet_objects<(S >= 8)>(P.scene, r, alive, rst, h, hinst);
-                } else if (depth == 1) {
-                    const bool go = alive && may_hit_scene(P.scene, r);
-                    if (__ballot(go) != 0) {
+                {
+                    const RenderParams& W = params_view(KP);  // walk
+                    float* q = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * W.lds_per_wave);
+                    uint2* stack = reinterpret_cast<uint2*>(q + kQueueFloats);
+                    if (depth == 1 && OBJ) {  // camera rays of an object group: one packet walk per member
                         RegStack rst(nullptr, lane);
-                        HybridStack hst(reinterpret_cast<float*>(stack), lane, P.scene.stack_cap, P.scene.packet_stack_regs);
-                        if (P.scene.stack_cap > P.scene.packet_stack_regs) trace_packet<false>(P.scene, r, go, hst, h);
-                        else trace_packet<(S >= 8)>(P.scene, r, go, rst, h);
+                        HybridStack hst(reinterpret_cast<float*>(stack), lane, W.scene.stack_cap, W.scene.packet_stack_regs);
+                        if (W.scene.stack_cap > W.scene.packet_stack_regs) trace_packet_objects<false>(W.scene, r, alive, hst, h, hinst);
+                        else trace_packet_objects<(S >= 8)>(W.scene, r, alive, rst, h, hinst);
+                    } else if (depth == 1) {
+                        const bool go = alive && may_hit_scene(W.scene, r);
+                        if (__ballot(go) != 0) {
+                            RegStack rst(nullptr, lane);
+                            HybridStack hst(reinterpret_cast<float*>(stack), lane, W.scene.stack_cap, W.scene.packet_stack_regs);
+                            if (W.scene.stack_cap > W.scene.packet_stack_regs) trace_packet<false>(W.scene, r, go, hst, h);
+                            else trace_packet<(S >= 8)>(W.scene, r, go, rst, h);
+                        }
+                    } else {
+                        // bounce rays: group walk (once per member of an object group)
+                        GroupHit gh;
+                        trace_objects<OBJ>(W.scene, r, alive, q, stack, lanes_lt, gh);
+                        h.t = gh.t; h.u = gh.u; h.v = gh.v; h.prim = gh.prim;
+                        hinst = gh.inst;
                     }
-                } else {
-                    // bounce rays: group walk (once per member of an object group)
-                    GroupHit gh;
-                    trace_objects<OBJ>(P.scene, r, alive, q, stack, lanes_lt, gh);
-                    h.t = gh.t; h.u = gh.u; h.v = gh.v; h.prim = gh.prim;
-                    hinst = gh.inst;
                 }
-                if (alive) alive = path_vertex<OBJ, N>(P.scene, h, depth, P.max_depth, rng, r, L, thr, primary_hit, hinst);
+                const RenderParams& V = params_view(KP);  // shade + bounce
+                if (alive) alive = path_vertex<OBJ, N>(V.scene, h, depth, max_depth, rng, r, L, thr, primary_hit, hinst);
             }
             cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
 #pragma unroll
             for (int c = 0; c < N; c++) add_samples_in_order<S>(acc[c], L[c], lane);
-            if (!RGB && P.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= P.s_end) chunk_flush(P, off, inpix && sub == 0, acc[0]);
+            const RenderParams& A = params_view(KP);  // accumulation
+            if (!RGB && A.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= s_end) chunk_flush(A, off, inpix && sub == 0, acc[0]);
         }
+        const RenderParams& E = params_view(KP);  // unit end
         if (inpix && sub == 0) {
-            if (RGB) pixel_state_store3(P, off, reinterpret_cast<const float (&)[3]>(acc[0]), cnt);
-            else pixel_state_store(P, off, acc[0], cnt);
+            if (RGB) pixel_state_store3(E, off, reinterpret_cast<const float (&)[3]>(acc[0]), cnt);
+            else pixel_state_store(E, off, acc[0], cnt);
         }
-        if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
+        if (E.tile_cost && lane == 0) atomicAdd(E.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
     }
-    if (lane == 0 && P.segments && segs) atomicAdd(P.segments, segs);
+    const RenderParams& Z = params_view(KP);
+    if (lane == 0 && Z.segments && segs) atomicAdd(Z.segments, segs);
 }
 
 // ---- staged ("wavefront") evaluation of the path extension: MP_FLAG_WAVEFRONT --------------------------------------
@@ -1558,23 +1603,29 @@ __device__ __forceinline__ uint32_t direction_bin(float dx, float dy, float dz) 
 // path p = (tile_local * ts*ts + (y - min_y) * ts + (x - min_x)) * sc + (s - s0)
 // Stage 1: camera rays, generated and walked as packets of 2x2 pixels x 16 samples like render_tiles_packet_kernel.
 template <bool LDS_STACK, bool OBJ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void wf_camera_kernel(WfParams P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void wf_camera_kernel(WfParams) {
     extern __shared__ __align__(16) unsigned char smem[];
+    typedef const __attribute__((address_space(4))) WfParams* kwf_t;
+    kwf_t KP = (kwf_t)__builtin_amdgcn_kernarg_segment_ptr();  // WfParams through short-lived views (see params_view)
+    const WfParams& P0 = kernarg_view<WfParams>(KP);
     constexpr int S = 16, BW = 2, BH = 2;
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const int pix = lane / S, sub = lane % S;
-    const uint32_t ts = P.tile_size, bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
-    const uint32_t n = P.st.n;
+    const uint32_t ts = P0.tile_size, bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P0.n_tiles * upt;
+    const uint32_t n = P0.st.n;
     const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
     unsigned long long segs = 0;  // camera segments of this wave (wave-uniform)
     for (uint32_t unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); unit < total; unit += n_waves) {
+        const WfParams& Pu = kernarg_view<WfParams>(KP);
         const uint32_t tile_l = unit / upt, b = unit % upt;
-        const mp_block T = P.tiles[tile_l];
+        const mp_block T = Pu.tiles[tile_l];
         const uint32_t px = T.min_x + (b % bx) * BW + static_cast<uint32_t>(pix % BW);
         const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
         const bool inpix = px < T.max_x && py < T.max_y;
-        const uint32_t pbase = ((tile_l * ts + (py - T.min_y)) * ts + (px - T.min_x)) * P.sc;
-        for (uint32_t sl0 = 0; sl0 < P.sc; sl0 += S) {
+        const uint32_t pbase = ((tile_l * ts + (py - T.min_y)) * ts + (px - T.min_x)) * Pu.sc;
+        const uint32_t sc_ = Pu.sc;
+        for (uint32_t sl0 = 0; sl0 < sc_; sl0 += S) {
+            const WfParams& P = kernarg_view<WfParams>(KP);  // one view per pass
             const uint32_t sl = sl0 + static_cast<uint32_t>(sub), s = P.s0 + sl;
             const bool slot = inpix && sl < P.sc;       // a path slot of the batch exists for this lane
             const bool act = slot && s < P.s_end;       // ... and holds a sample of this launch
@@ -1630,7 +1681,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) voi
             }
         }
     }
-    if (lane == 0 && P.segments && segs) atomicAdd(P.segments, segs);
+    if (lane == 0 && P0.segments && segs) atomicAdd(P0.segments, segs);
 }
 
 // Stage 2: one thread per path: shade the hit of segment P.depth, draw the bounce ray, count it under its sort key.
@@ -1817,14 +1868,18 @@ struct TraceParams {
 };
 
 template <bool OBJ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void trace_rays_kernel(TraceParams P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void trace_rays_kernel(TraceParams) {
     extern __shared__ __align__(16) unsigned char smem[];
+    typedef const __attribute__((address_space(4))) TraceParams* ktrace_t;
+    ktrace_t KP = (ktrace_t)__builtin_amdgcn_kernarg_segment_ptr();  // TraceParams through short-lived views (see params_view)
+    const TraceParams& P0 = kernarg_view<TraceParams>(KP);
     const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
-    float* q = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P.lds_per_wave);
+    float* q = reinterpret_cast<float*>(smem + static_cast<size_t>(wave) * P0.lds_per_wave);
     uint2* stack = reinterpret_cast<uint2*>(q + kQueueFloats);
-    const uint64_t chunks = (P.n + 63) / 64;
+    const uint64_t chunks = (P0.n + 63) / 64;
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * (blockDim.x >> 6);
     for (uint64_t chunk = static_cast<uint64_t>(blockIdx.x) * (blockDim.x >> 6) + wave; chunk < chunks; chunk += stride) {
+        const TraceParams& P = kernarg_view<TraceParams>(KP);  // one view per chunk of 64 rays
         const uint64_t i = chunk * 64 + lane;
         const bool act = i < P.n;
         Ray r0;
@@ -2084,10 +2139,10 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         else hipLaunchKernelGGL((render_tiles_packet_kernel<SV, false, W>), dim3(grid), dim3(256), 0, st, P);           \
     } while (0)
     if (obj) {
-        if (S == 16 && lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<16, true, 7, true>), dim3(grid), dim3(256), plds, st, P);
-        else if (S == 16) hipLaunchKernelGGL((render_tiles_packet_kernel<16, false, 7, true>), dim3(grid), dim3(256), 0, st, P);
-        else if (lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<1, true, 7, true>), dim3(grid), dim3(256), plds, st, P);
-        else hipLaunchKernelGGL((render_tiles_packet_kernel<1, false, 7, true>), dim3(grid), dim3(256), 0, st, P);
+        if (S == 16 && lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<16, true, 6, true>), dim3(grid), dim3(256), plds, st, P);
+        else if (S == 16) hipLaunchKernelGGL((render_tiles_packet_kernel<16, false, 6, true>), dim3(grid), dim3(256), 0, st, P);
+        else if (lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<1, true, 6, true>), dim3(grid), dim3(256), plds, st, P);
+        else hipLaunchKernelGGL((render_tiles_packet_kernel<1, false, 6, true>), dim3(grid), dim3(256), 0, st, P);
     } else if (S == 64) MP_LAUNCH_PACKET(64, 7);
     else if (S == 32 && big) MP_LAUNCH_PACKET(32, 8);
     else if (S == 32) MP_LAUNCH_PACKET(32, 7);
