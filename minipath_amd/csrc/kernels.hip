@@ -837,7 +837,37 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 const uint32_t cl = uniform_u(blink);
                 if (cl == MP_LINK_NULL) return;  // Null links are skipped at pop in the reference (:49)
                 float t1, t2;
-                slab<PATCH_NAN, OCT>(b0, b1, b2, b3, b4, b5, r, lim, t1, t2);
+                if (PATCH_NAN) {
+                    slab<PATCH_NAN, OCT>(b0, b1, b2, b3, b4, b5, r, lim, t1, t2);
+                } else {
+                    // aabb.rs:254-284 in two stages (round 3): t1 = max(lo.x, 0, lo.y, lo.z) and t2 = min(hi.x, limit, hi.y, hi.z) are
+                    // the same numbers in any order of evaluation (max / min of the same operands), and max(lo.x, lo.y, 0) >
+                    // min(hi.x, hi.y, limit) already decides t1 > t2.  Counted on the metric's frame (profiles/r03_notes.md): for
+                    // 60 % of the child boxes a packet tests, no ray survives the x and y slabs -- the z slab and the rest are
+                    // skipped for the whole wave (11 instead of 17 VALU).  Which two axes go first is a compile-time choice.
+#ifndef MP_SLAB_LAST
+#define MP_SLAB_LAST 2  // the axis whose slab is tested last (A/B-measured: profiles/r03_notes.md)
+#endif
+                    constexpr int A2 = MP_SLAB_LAST, A0 = (A2 + 1) % 3, A1 = (A2 + 2) % 3;
+                    const float bn[3] = {b0, b1, b2}, bx3[3] = {b3, b4, b5}, ro[3] = {r.ox, r.oy, r.oz}, ri[3] = {r.ix, r.iy, r.iz};
+                    const float a0_ = (bn[A0] - ro[A0]) * ri[A0], c0_ = (bx3[A0] - ro[A0]) * ri[A0];
+                    const float a1_ = (bn[A1] - ro[A1]) * ri[A1], c1_ = (bx3[A1] - ro[A1]) * ri[A1];
+                    float lo0, hi0, lo1, hi1;
+                    if (OCT >= 0) {
+                        lo0 = ((OCT >> A0) & 1) ? c0_ : a0_; hi0 = ((OCT >> A0) & 1) ? a0_ : c0_;
+                        lo1 = ((OCT >> A1) & 1) ? c1_ : a1_; hi1 = ((OCT >> A1) & 1) ? a1_ : c1_;
+                    } else {
+                        lo0 = fminf(a0_, c0_); hi0 = fmaxf(a0_, c0_); lo1 = fminf(a1_, c1_); hi1 = fmaxf(a1_, c1_);
+                    }
+                    const float t1p = fmaxf(fmaxf(lo0, 0.0f), lo1), t2p = fminf(fminf(hi0, lim), hi1);
+                    if (__ballot(t1p <= t2p) == 0) return;
+                    const float a2_ = (bn[A2] - ro[A2]) * ri[A2], c2_ = (bx3[A2] - ro[A2]) * ri[A2];
+                    float lo2, hi2;
+                    if (OCT >= 0) { lo2 = ((OCT >> A2) & 1) ? c2_ : a2_; hi2 = ((OCT >> A2) & 1) ? a2_ : c2_; }
+                    else { lo2 = fminf(a2_, c2_); hi2 = fmaxf(a2_, c2_); }
+                    t1 = fmaxf(t1p, lo2);
+                    t2 = fminf(t2p, hi2);
+                }
                 const uint64_t okm = __ballot(t1 <= t2);
                 if (okm != 0) {
                     st.push(sp, cl, cslot, okm);
