@@ -2145,6 +2145,10 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     int S = nspp >= 16 ? 16 : nspp >= 8 ? 8 : nspp >= 4 ? 4 : nspp >= 2 ? 2 : 1;
     // small launches (a rank's shard of a multi-GPU frame): 2-pixel units, so that the tail of the launch is half as long
     if (nspp >= 32 && units * 16u < static_cast<uint64_t>(L.cu_count) * 32u * 24u) S = 32;
+    // scenes whose traversal arrays exceed the 16 KB scalar data cache by far run 8 waves per SIMD, and at many samples per pixel
+    // 32 samples of a pixel in flight (a 1x2 pixel footprint: measured 42.1 against 42.6 ms on the metric's frame, tools/s_sweep.py)
+    const bool big = (static_cast<uint64_t>(L.scene.inner_count) * 256u + static_cast<uint64_t>(L.scene.packet_count) * 384u) > (1u << 20);
+    if (big && nspp >= 128) S = 32;
     if (L.packet_samples) S = static_cast<int>(std::min<uint32_t>(L.packet_samples, 64u));
     const bool obj = L.scene.inst_count != 0u;  // object group: one packet walk per member (instantiated for 16 and 1 samples in flight)
     if (obj) S = (S >= 16 && nspp >= 16) ? 16 : 1;
@@ -2161,8 +2165,6 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         return check(hipGetLastError(), "render_tiles_packet2_kernel launch", err);
     }
     const uint32_t grid = static_cast<uint32_t>(std::min<uint64_t>(want * S, static_cast<uint64_t>(L.cu_count) * per_cu));
-    // scenes whose traversal arrays exceed the 16 KB scalar data cache by far run 8 waves per SIMD
-    const bool big = (static_cast<uint64_t>(L.scene.inner_count) * 256u + static_cast<uint64_t>(L.scene.packet_count) * 384u) > (1u << 20);
 #define MP_LAUNCH_PACKET(SV, W)                                                                                         \
     do {                                                                                                                \
         if (lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<SV, true, W>), dim3(grid), dim3(256), plds, st, P); \

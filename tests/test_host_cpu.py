@@ -27,6 +27,14 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in _lib.lib().mp_version()
 
 
+def test_integration_doc_binds_every_symbol():
+    """INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add: it must name exactly the header's symbols."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "minipath_hip.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(mp_[a-z0-9_]+)\s*\(", hdr)) - {"mp_tile_started_cb", "mp_tile_finished_cb"}
+    bound = set(re.findall(r"pub fn (mp_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "INTEGRATION.md")).read()))
+    assert declared == bound, declared ^ bound
+
+
 def _assert_same_bvh(prod: mp.TriangleBvh, orc):
     i = prod.info()
     assert (i.inner_count, i.packet_count, i.vertex_count, i.depth) == (orc.n_inner, orc.n_packets, orc.n_vertices, orc.depth)
