@@ -6,9 +6,12 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd "$R"
-if [ "$1" = "collect" ]; then
+collect_counters() {
   python3 tools/collect_counters.py "atrium256=atrium 1920x1080 256spp tile64 depth0 packets" "atrium_d8=atrium 1920x1080 64spp tile64 depth8 packets" \
       "teapot256=teapot.obj 1920x1080 256spp tile64 depth0 packets" "teapot_d8=teapot.obj 1920x1080 256spp tile64 depth8 packets" > /dev/null
+}
+if [ "$1" = "collect" ]; then
+  collect_counters
   for t in atrium256 atrium_d8 teapot256 teapot_d8; do
     cp gpurun_out/cnt_${t}_kernel_stats.csv profiles/r03_${t}_kernel_stats.csv
     cp gpurun_out/cnt_${t}.txt profiles/r03_${t}_counters.txt
@@ -21,6 +24,7 @@ bash tools/gpu_counters.sh atrium256 render_tiles_packet_kernel
 bash tools/gpu_counters.sh atrium_d8 render_paths_kernel --spp 64 --depth 8
 bash tools/gpu_counters.sh teapot256 render_tiles_packet_kernel --scene teapot
 bash tools/gpu_counters.sh teapot_d8 render_paths_kernel --scene teapot --depth 8
+collect_counters   # on the box too: the default bench line below then carries the counter-derived figures of THIS build
 python3 bench.py > gpurun_out/bench_r03_final.log 2>&1
 grep '^{' gpurun_out/bench_r03_final.log > gpurun_out/bench_r03_final.json
 cut -c1-600 gpurun_out/bench_r03_final.json

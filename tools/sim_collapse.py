@@ -12,6 +12,7 @@ The walk below is a numpy model (f32, unfused triangle test: counts only, not a 
 8-lane-group kernel's unit of work and (b) 64 camera rays per walk = the packet kernel.  Diagnostics only.
 
 usage: sim_collapse.py [atrium|teapot] [detail] [n_rays]
+       sim_collapse.py --packet-studies [atrium|teapot]   (interval rejection / two-slab exit of the packet walk's child tests)
 """
 import sys, os, time
 import numpy as np
@@ -239,6 +240,69 @@ def camera_packets(scene, npk, rng, w=1920, h=1080):
     return out
 
 
+
+def packet_studies(scene="atrium", detail=1.0, npk=150):
+    """Round-3 studies on the child-box tests of the packet walk (64 camera rays per walk, wide tree): (a) how many of the children a
+    packet does NOT push could a conservative test on the packet's bounds (interval arithmetic on min / max of origins and inverse
+    directions: monotone IEEE operations, exact) reject; (b) for how many does no ray survive two of the three slabs."""
+    ref = RefTree(*load(scene, detail))
+    rng = np.random.default_rng(1)
+    pk = camera_packets(scene, npk, rng)
+    nodes, root, _ = build_device(ref, "area", 8)
+    tot = dict(visits=0, boxes=0, pushes=0, nopush=0, interval_reject=0, xy=0, xz=0, yz=0)
+
+    def two(lo, hi, lim, mask, a, b):
+        t1 = np.maximum(np.maximum(lo[..., a], 0), lo[..., b]); t2 = np.minimum(np.minimum(hi[..., a], lim[:, None]), hi[..., b])
+        return (t1 <= t2) & mask[:, None]
+
+    for o, d in pk:
+        P = 64
+        with np.errstate(divide="ignore"):
+            inv = np.where(d == 0, F(np.inf), F(1) / d).astype(F)
+        sg = np.sign(inv)
+        uniform = all((sg[:, k] == sg[0, k]).all() for k in range(3)) and np.isfinite(inv).all()
+        omin, omax, imin, imax = o.min(0), o.max(0), inv.min(0), inv.max(0)
+        best = np.full(P, np.finfo(F).max, F)
+        stack = [(root, np.ones(P, bool), None)]
+        while stack:
+            link, mask, box = stack.pop()
+            if box is not None:
+                t1, _ = slab(box[None, :], o, inv, best); mask = mask & ~(t1[:, 0] > best)
+            if not mask.any():
+                continue
+            if link >= 0:
+                boxes, links = nodes[link]
+                tot["visits"] += 1; tot["boxes"] += len(links)
+                with np.errstate(invalid="ignore"):
+                    a = (boxes[None, :, :3] - o[:, None, :]) * inv[:, None, :]; c = (boxes[None, :, 3:] - o[:, None, :]) * inv[:, None, :]
+                lo, hi = np.minimum(a, c), np.maximum(a, c)
+                t1, t2 = slab(boxes, o, inv, best)
+                ok = (t1 <= t2) & mask[:, None]
+                rxy, rxz, ryz = two(lo, hi, best, mask, 0, 1), two(lo, hi, best, mask, 0, 2), two(lo, hi, best, mask, 1, 2)
+                for cc in range(len(links)):
+                    if ok[:, cc].any():
+                        stack.append((int(links[cc]), ok[:, cc].copy(), boxes[cc])); tot["pushes"] += 1
+                        continue
+                    tot["nopush"] += 1
+                    tot["xy"] += not rxy[:, cc].any(); tot["xz"] += not rxz[:, cc].any(); tot["yz"] += not ryz[:, cc].any()
+                    if uniform:
+                        b = boxes[cc]; L = []; U = []
+                        for k in range(3):
+                            pos = sg[0, k] > 0
+                            near, far = (b[k], b[3 + k]) if pos else (b[3 + k], b[k])
+                            a_lo, a_hi, b_lo, b_hi = F(near - omax[k]), F(near - omin[k]), F(far - omax[k]), F(far - omin[k])
+                            if pos:
+                                L.append(min(F(a_lo * imin[k]), F(a_lo * imax[k]))); U.append(max(F(b_hi * imin[k]), F(b_hi * imax[k])))
+                            else:
+                                L.append(min(F(a_hi * imin[k]), F(a_hi * imax[k]))); U.append(max(F(b_lo * imin[k]), F(b_lo * imax[k])))
+                        tot["interval_reject"] += max(max(L), 0) > min(U)
+            else:
+                v0, e1, e2 = ref.leaf[-1 - link]
+                t = mt(v0, e1, e2, o, d); t = np.where(mask[:, None], t, np.inf)
+                best = np.minimum(best, t.min(axis=1).astype(F))
+    print("per packet:", {k: round(v / len(pk), 2) for k, v in tot.items()})
+
+
 def new_cnt():
     return {"pops": 0, "culls": 0, "nodes": 0, "boxes": 0, "pushes": 0, "leaves": 0, "tris": 0, "packets": 0, "hist": np.zeros(65, np.int64)}
 
@@ -292,4 +356,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--packet-studies":
+        packet_studies(*(sys.argv[2:3] or ["atrium"]))
+    else:
+        main()
