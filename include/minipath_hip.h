@@ -203,8 +203,10 @@ int mp_ctx_device(const mp_ctx *ctx, int *device_id, int *cu_count);
  * rest of the scene's stack bound lives in LDS.  "packet_samples_in_flight" (0 = automatic, or 1, 2, 4, ... 64): samples of one pixel
  * a wavefront traces per pass (64 / value pixels side by side); sets the size of a work unit.  "packet_rays_per_lane" (1 default,
  * or 2): 2 = 128-ray walks, two rays per lane (measured slower on MI355X; kept as the measured alternative).  "blocks_per_cu"
- * (0 = as many as fit, or 1..8): resident workgroups per CU, a diagnostic knob for occupancy studies.  Results never depend on
- * any of them (tests sweep them). */
+ * (0 = as many as fit, or 1..8): resident workgroups per CU, a diagnostic knob for occupancy studies.  "paths_pooled" (MP_FLAG_PATHS
+ * without MP_FLAG_WAVEFRONT; 1 default): 0 = one pass of 8 samples per walk of the bounce rays, 2 / 3 = two / up to four passes share
+ * one walk over a per-wave ray queue in global memory (fewer idle lane groups at the end of every walk), 1 = the latter for scenes
+ * whose traversal arrays exceed 1 MB.  Results never depend on any of them (tests sweep them). */
 int mp_ctx_set_option(mp_ctx *ctx, const char *key, int value);
 
 /* ---- camera.rs ------------------------------------------------------------------------------------------ */

@@ -35,6 +35,14 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Global memory written by some lanes of ONE wavefront and read by others (the pooled path kernel's ray queue): the wave's
+// outstanding stores are waited for (workgroup-scope release / acquire; the vector L1 of a CU is coherent for its own waves).
+__device__ __forceinline__ void wave_mem_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // ---- 8-lane group collectives on DPP (no LDS traffic) ---------------------------------------------------------
 // row_half_mirror (0x141) pairs lane i with 7-i inside every group of 8; quad_perm [1,0,3,2] (0xB1) and
 // [2,3,0,1] (0x4E) finish the butterfly inside each quad.  All 8 lanes end with the group's reduction.
@@ -174,15 +182,17 @@ __device__ __forceinline__ uint64_t mask_ge(float a, float b) { return __builtin
 // impl Object for TriangleBvh::intersect, ray_bvh_intersection.rs:26-96, for 8 rays at a time.
 // BFE: the count of passing children below a lane from v_bfe_u32 instead of a loop-invariant mask register (one VGPR less, one
 // VALU more per node step): pays in trace_rays_kernel, which sits at the 64-VGPR cap, and costs 0.5 % in render_paths_kernel.
-template <bool PATCH_NAN, bool BFE>
+// QS = queue stride = ray slots.  QS == 64: the wave's LDS queue (rows ox,oy,oz,dx,dy,dz; the hit aliases rows 0..3; inverse
+// directions computed here, one slot per lane).  QS > 64: the pooled path kernel's queue in global memory (rows 0..5 origin and
+// direction, 6..8 inverse direction as Ray::new has it, 9..12 the hit: the rays are needed again for shading).
+template <bool PATCH_NAN, bool BFE, int QS = 64>
 __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __restrict__ q, uint2* __restrict__ stack_base,
                                                 int nrays) {
+    constexpr int HB = QS == 64 ? 0 : 9;  // first hit row
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const int g = lane >> 3, li = lane & 7;
     uint2* stack = stack_base + g * sc.stack_cap;
-    const uint64_t groups_below = (1ull << (g * 8)) - 1ull;
     const uint32_t lanes_below = (1u << li) - 1u;
-    const int src_base = lane & ~7;
 
     int slot = -1, sp = 0, head = 0;
     uint32_t pk = 0, pk_end = 0, seq = 0;
@@ -199,8 +209,8 @@ __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __res
     // inv_direction as Ray::new has it (geometry/mod.rs:49-53) for the ray in queue slot `lane`, computed ONCE here for all 64
     // slots in parallel (three IEEE divisions per call instead of three per refill step); a group fetches its ray's inverse with
     // ds_bpermute when it pulls the ray.  Not queued in LDS: three rows more per wave would cost a resident wave on deep trees.
-    float pix, piy, piz;
-    {
+    float pix = 0.0f, piy = 0.0f, piz = 0.0f;
+    if (QS == 64) {
         const float qx = q[3 * 64 + lane], qy = q[4 * 64 + lane], qz = q[5 * 64 + lane];
         pix = (qx == 0.0f) ? INFINITY : 1.0f / qx; piy = (qy == 0.0f) ? INFINITY : 1.0f / qy; piz = (qz == 0.0f) ? INFINITY : 1.0f / qz;
     }
@@ -214,30 +224,39 @@ __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __res
             float tmin = group_min_t(tl);
             uint32_t key = (pkl != kNoPrim && tl == tmin) ? ((seql << 3) | static_cast<uint32_t>(li)) : 0xFFFFFFFFu;
             uint32_t kmin = group_min_u(key);
-            int wl = src_base | static_cast<int>(kmin & 7u);
-            float wu = __shfl(ul, wl), wv = __shfl(vl, wl);
-            uint32_t wp = static_cast<uint32_t>(__shfl(static_cast<int>(pkl), wl));
+            // winner's lane, recomputed from the lane id where it is needed (ds_bpermute takes a byte address: lane * 4)
+            const int wl4 = (((static_cast<int>(threadIdx.x) & 56) | static_cast<int>(kmin & 7u))) << 2;
+            const float wu = __int_as_float(__builtin_amdgcn_ds_bpermute(wl4, __float_as_int(ul)));
+            const float wv = __int_as_float(__builtin_amdgcn_ds_bpermute(wl4, __float_as_int(vl)));
+            const uint32_t wp = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(wl4, static_cast<int>(pkl)));
             if (li == 0) {
                 bool hit = kmin != 0xFFFFFFFFu;
-                q[0 * 64 + slot] = hit ? tmin : FLT_MAX;
-                q[1 * 64 + slot] = as_f(hit ? (wp * 8u + (kmin & 7u)) : kNoPrim);
-                q[2 * 64 + slot] = wu;
-                q[3 * 64 + slot] = wv;
+                q[(HB + 0) * QS + slot] = hit ? tmin : FLT_MAX;
+                q[(HB + 1) * QS + slot] = as_f(hit ? (wp * 8u + (kmin & 7u)) : kNoPrim);
+                q[(HB + 2) * QS + slot] = wu;
+                q[(HB + 3) * QS + slot] = wv;
             }
             slot = -1;
         }
         // -- idle groups pull the next rays of the queue (wave-uniform head, no atomics)
         uint64_t idle = __ballot(slot < 0);
         if (idle != 0) {
+            // the mask of the groups below this one is needed once per ray: recomputed here (3 VALU) rather than kept in -- or spilled
+            // from -- two registers for the whole walk
+            int g_ = g;
+            asm volatile("" : "+v"(g_));
+            const uint64_t groups_below = (1ull << (g_ * 8)) - 1ull;
             uint64_t gm = idle & 0x0101010101010101ull;
             int mine = head + __popcll(gm & groups_below);
             head += __popcll(gm);
             // (ds_bpermute reads the source lane's register whether or not that lane is enabled; an out-of-range `mine` wraps)
-            const float fix = __shfl(pix, mine & 63), fiy = __shfl(piy, mine & 63), fiz = __shfl(piz, mine & 63);
+            float fix = 0.0f, fiy = 0.0f, fiz = 0.0f;
+            if (QS == 64) { fix = __shfl(pix, mine & 63); fiy = __shfl(piy, mine & 63); fiz = __shfl(piz, mine & 63); }
             if (slot < 0 && mine < nrays) {
                 slot = mine;
-                ox = q[0 * 64 + mine]; oy = q[1 * 64 + mine]; oz = q[2 * 64 + mine];
-                dx = q[3 * 64 + mine]; dy = q[4 * 64 + mine]; dz = q[5 * 64 + mine];
+                ox = q[0 * QS + mine]; oy = q[1 * QS + mine]; oz = q[2 * QS + mine];
+                dx = q[3 * QS + mine]; dy = q[4 * QS + mine]; dz = q[5 * QS + mine];
+                if (QS != 64) { fix = q[6 * QS + mine]; fiy = q[7 * QS + mine]; fiz = q[8 * QS + mine]; }
                 ix = fix; iy = fiy; iz = fiz;
                 best_t = FLT_MAX; tl = FLT_MAX; ul = 0; vl = 0; pkl = kNoPrim; seql = 0; seq = 0;
                 pk = pk_end = 0;
@@ -321,6 +340,21 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
     const bool inf = lane < nrays && (fabsf(ix) == INFINITY || fabsf(iy) == INFINITY || fabsf(iz) == INFINITY);
     if (__ballot(inf) != 0) trace_wave_impl<true, BFE>(sc, q, stack_base, nrays);
     else trace_wave_impl<false, BFE>(sc, q, stack_base, nrays);
+}
+
+// ... and for the pooled path kernel's queue of QS > 64 slots in global memory (inverse directions in rows 6..8)
+template <int QS>
+__device__ __forceinline__ void trace_wave_pool(const DevScene& sc, float* __restrict__ q, uint2* __restrict__ stack_base, int nrays) {
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    bool inf = false;
+#pragma unroll
+    for (int k = 0; k < QS / 64; k++) {
+        const int slot = lane + 64 * k;
+        if (slot < nrays)
+            inf = inf || fabsf(q[6 * QS + slot]) == INFINITY || fabsf(q[7 * QS + slot]) == INFINITY || fabsf(q[8 * QS + slot]) == INFINITY;
+    }
+    if (__ballot(inf) != 0) trace_wave_impl<true, true, QS>(sc, q, stack_base, nrays);
+    else trace_wave_impl<false, true, QS>(sc, q, stack_base, nrays);
 }
 
 // Exact conservative pre-test against the union of the root node's child boxes (DevScene::pre_min/pre_max): every
@@ -504,6 +538,8 @@ struct RenderParams {
     uint32_t lds_per_wave;
     uint32_t max_depth;   // path extension only
     unsigned long long* segments;  // path extension: ray segments traced (Object::intersect calls), may be null
+    float* pool;           // pooled path kernel: per-wave workspace (ray queue + parked path state), pool_stride floats per wave
+    uint32_t pool_stride;
 };
 
 // worker.rs:40-44 with the running state of a pixel carried across launches (MP_FLAG_ACCUMULATE): rgb = sequential sample sum,
@@ -1576,6 +1612,188 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_PATHS_WP
     if (lane == 0 && Z.segments && segs) atomicAdd(Z.segments, segs);
 }
 
+// ---- pooled form of render_paths_kernel (round 3) ----------------------------------------------------------------------------
+// The fused kernel above traces the bounce rays of ONE pass (8 pixels x 8 samples = at most 64 rays) per call of the 8-lane-group
+// walk, and a ray's walk takes 10 to 80 steps: when the queue runs dry the groups idle until the slowest ray of the call finishes
+// -- 13 % of the group-iterations of a 64-ray call on the stand-in, 6.5 % of a 256-ray call (tools/sim_collapse.py's traces;
+// profiles/r03_notes.md).  Here a wave keeps NSUB passes in flight: per bounce, the passes are shaded one after the other, lane =
+// path, and their rays are compacted into ONE queue of up to 64 * NSUB rays that the walk drains in a single call.  The state of
+// the passes that are not being shaded -- RNG, radiance, throughput, flags: 11 dwords per path -- and the queue itself (origin,
+// direction, inverse direction, hit: 13 dwords per ray) live in a per-wave slab of global memory (RenderParams::pool, 24 dwords
+// x 64 * NSUB per wave, L2-resident): the "rays laid out SoA + stream compaction" of the north star, inside one persistent wave.
+// Nothing of a path is live in registers across the walk, so the kernel fits 64 VGPRs = 8 waves per SIMD.
+// Per path the operations, their order and the RNG stream are those of render_paths_kernel (same path_vertex, same walks, samples
+// added in index order): the frame is bit-identical (tests run both kernels on the same cases).
+#ifndef MP_POOL_WPE
+#define MP_POOL_WPE 8
+#endif
+constexpr int kPoolQueueRows = 13, kPoolStateRows = 11;
+__host__ __device__ constexpr uint32_t pool_floats_per_wave(int nsub) { return static_cast<uint32_t>((kPoolQueueRows + kPoolStateRows) * 64 * nsub); }
+constexpr uint32_t kPoolAlive = 1u, kPoolPrimary = 2u, kPoolQueued = 4u;  // flags word: bits 0..2, queue slot << 8
+
+template <int NSUB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_POOL_WPE, 8))) void render_paths_pooled_kernel(RenderParams) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    MP_KERNEL_PARAMS;
+    constexpr int S = 8, BW = 4, BH = 2, QN = 64 * NSUB;
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);  // uniform: the pool / stack pointers stay in SGPRs
+    const int pix = lane / S, sub = lane % S;
+    const uint64_t pixel_lanes = ((1ull << S) - 1ull) << (lane & ~(S - 1));
+    const uint64_t lanes_lt = (1ull << lane) - 1ull;
+    unsigned long long segs = 0;  // wave-uniform
+    uint32_t qstate = blockIdx.x % kWorkQueues;
+    float* q;        // ray queue: kPoolQueueRows rows x QN slots
+    uint32_t* park;  // parked path state: kPoolStateRows rows x QN (slot = pass * 64 + lane): rng 8, L, thr, flags
+    uint2* stack;
+    {
+        const RenderParams& P0 = params_view(KP);
+        q = P0.pool + static_cast<size_t>(blockIdx.x * 4u + static_cast<uint32_t>(wave)) * P0.pool_stride;
+        park = reinterpret_cast<uint32_t*>(q + kPoolQueueRows * QN);
+        stack = reinterpret_cast<uint2*>(smem + static_cast<size_t>(wave) * P0.lds_per_wave);
+    }
+    auto park_store = [&](int j, const Rng& rng, float L, float thr, uint32_t flags) {
+        uint32_t* p = park + j * 64 + lane;
+        p[0 * QN] = static_cast<uint32_t>(rng.s0); p[1 * QN] = static_cast<uint32_t>(rng.s0 >> 32);
+        p[2 * QN] = static_cast<uint32_t>(rng.s1); p[3 * QN] = static_cast<uint32_t>(rng.s1 >> 32);
+        p[4 * QN] = static_cast<uint32_t>(rng.s2); p[5 * QN] = static_cast<uint32_t>(rng.s2 >> 32);
+        p[6 * QN] = static_cast<uint32_t>(rng.s3); p[7 * QN] = static_cast<uint32_t>(rng.s3 >> 32);
+        p[8 * QN] = as_u(L); p[9 * QN] = as_u(thr); p[10 * QN] = flags;
+    };
+    // bounce ray of a path that is still alive: into the queue (compacted over the lanes whose ray can reach the scene at all)
+    auto push_ray = [&](const DevScene& sc, const Ray& r, bool alive, uint32_t& nq, uint32_t& flags) {
+        const bool queued = alive && may_hit_scene(sc, r);
+        const uint64_t am = __ballot(queued);
+        const uint32_t slot = nq + static_cast<uint32_t>(__popcll(am & lanes_lt));
+        if (queued) {
+            q[0 * QN + slot] = r.ox; q[1 * QN + slot] = r.oy; q[2 * QN + slot] = r.oz;
+            q[3 * QN + slot] = r.dx; q[4 * QN + slot] = r.dy; q[5 * QN + slot] = r.dz;
+            q[6 * QN + slot] = r.ix; q[7 * QN + slot] = r.iy; q[8 * QN + slot] = r.iz;
+            flags |= kPoolQueued | (slot << 8);
+        }
+        nq += static_cast<uint32_t>(__popcll(am));
+    };
+    for (;;) {
+        const RenderParams& P = params_view(KP);  // unit setup
+        const uint32_t ts = P.tile_size;
+        const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by, total = P.n_tiles * upt;
+        MP_NEXT_UNIT(unit)
+        const uint32_t b = unit % upt;
+        const uint32_t tile_i = P.tile_order ? P.tile_order[unit / upt] : unit / upt;
+        const uint64_t t_unit = P.tile_cost ? __builtin_readcyclecounter() : 0;
+        const mp_block T = P.tiles[tile_i];
+        const uint32_t px = T.min_x + (b % bx) * BW + static_cast<uint32_t>(pix % BW);
+        const uint32_t py = T.min_y + (b / bx) * BH + static_cast<uint32_t>(pix / BW);
+        const bool inpix = px < T.max_x && py < T.max_y;
+        if (__ballot(inpix) == 0) continue;
+        const size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
+        float acc, cnt;  // pixel_sum (grey table: one channel) and alpha (worker.rs:40)
+        pixel_state_load(P, off, inpix, sub == 0, acc, cnt);
+        const uint32_t s_begin = P.s_begin, s_end = P.s_end, max_depth = P.max_depth;
+        // a batch = NSUB consecutive passes of S samples, aligned in the absolute sample index (so that a 256-sample chunk boundary
+        // of MP_FLAG_CHUNKED_SUM never falls inside a batch); samples outside [s_begin, s_end) add +0.0, which is exact
+        for (uint32_t s0 = s_begin & ~static_cast<uint32_t>(S * NSUB - 1); s0 < s_end; s0 += S * NSUB) {
+            uint32_t nq = 0, na = 0;  // rays in the queue / paths alive, over all passes of the batch (wave-uniform)
+            // ---- segment 1: camera rays of every pass as one packet each, then the first vertex
+#pragma nounroll
+            for (int j = 0; j < NSUB; j++) {
+                const uint32_t s = s0 + static_cast<uint32_t>(j * S + sub);
+                const bool act = inpix && s >= s_begin && s < s_end;
+                Rng rng;
+                rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+                Ray r;
+                r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+                {
+                    const RenderParams& G = params_view(KP);  // ray generation
+                    if (act) {
+                        rng_seed(rng, sample_key(G.gen, px, py, s));
+                        sample_ray_rng(G.gen, px, py, rng, r);
+                    }
+                }
+                segs += static_cast<unsigned long long>(__popcll(__ballot(act)));
+                PacketHit h;
+                h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
+                {
+                    const RenderParams& W = params_view(KP);  // walk
+                    const bool go = act && may_hit_scene(W.scene, r);
+                    if (__ballot(go) != 0) {
+                        RegStack rst(nullptr, lane);
+                        HybridStack hst(reinterpret_cast<float*>(stack), lane, W.scene.stack_cap, W.scene.packet_stack_regs);
+                        if (W.scene.stack_cap > W.scene.packet_stack_regs) trace_packet<false>(W.scene, r, go, hst, h);
+                        else trace_packet<true>(W.scene, r, go, rst, h);
+                    }
+                }
+                const RenderParams& V = params_view(KP);  // shade + bounce
+                float L[1] = {0.0f}, thr[1] = {1.0f};
+                bool alive = act, primary_hit = false;
+                if (alive) alive = path_vertex<false, 1>(V.scene, h, 1u, max_depth, rng, r, L, thr, primary_hit);
+                uint32_t flags = (alive ? kPoolAlive : 0u) | (primary_hit ? kPoolPrimary : 0u);
+                push_ray(V.scene, r, alive, nq, flags);
+                na += static_cast<uint32_t>(__popcll(__ballot(alive)));
+                park_store(j, rng, L[0], thr[0], flags);
+            }
+            // ---- segments 2 .. max_depth: one walk over the rays of all passes, then the passes' vertices one after the other
+            for (uint32_t depth = 2; depth <= max_depth && na != 0u; depth++) {
+                segs += na;
+                wave_mem_sync();  // the queue written above is read by other lanes of this wave
+                if (nq != 0u) {
+                    const RenderParams& W = params_view(KP);
+                    trace_wave_pool<QN>(W.scene, q, stack, static_cast<int>(nq));
+                }
+                wave_mem_sync();
+                nq = 0;
+                na = 0;
+    #pragma nounroll
+            for (int j = 0; j < NSUB; j++) {
+                    const uint32_t* p = park + j * 64 + lane;
+                    uint32_t flags = p[10 * QN];
+                    bool alive = (flags & kPoolAlive) != 0u;
+                    if (__ballot(alive) == 0) continue;  // the whole pass is finished: its parked L / flags stay as they are
+                    Rng rng;
+                    rng.s0 = p[0 * QN] | (static_cast<uint64_t>(p[1 * QN]) << 32); rng.s1 = p[2 * QN] | (static_cast<uint64_t>(p[3 * QN]) << 32);
+                    rng.s2 = p[4 * QN] | (static_cast<uint64_t>(p[5 * QN]) << 32); rng.s3 = p[6 * QN] | (static_cast<uint64_t>(p[7 * QN]) << 32);
+                    float L[1] = {as_f(p[8 * QN])}, thr[1] = {as_f(p[9 * QN])};
+                    bool primary_hit = (flags & kPoolPrimary) != 0u;
+                    Ray r;
+                    r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;
+                    PacketHit h;
+                    h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim;
+                    if (alive && (flags & kPoolQueued)) {  // the ray this path shot and what it hit (a ray that was not queued missed)
+                        const uint32_t slot = flags >> 8;
+                        r.ox = q[0 * QN + slot]; r.oy = q[1 * QN + slot]; r.oz = q[2 * QN + slot];
+                        r.dx = q[3 * QN + slot]; r.dy = q[4 * QN + slot]; r.dz = q[5 * QN + slot];
+                        h.t = q[9 * QN + slot]; h.prim = as_u(q[10 * QN + slot]); h.u = q[11 * QN + slot]; h.v = q[12 * QN + slot];
+                    }
+                    const RenderParams& V = params_view(KP);
+                    if (alive) alive = path_vertex<false, 1>(V.scene, h, depth, max_depth, rng, r, L, thr, primary_hit);
+                    flags = (alive ? kPoolAlive : 0u) | (primary_hit ? kPoolPrimary : 0u);
+                    // every lane of this pass has read its old slot (the loads above feed the stores below); the new slots are no
+                    // higher than the old ones of this pass, so later passes' rays and hits are untouched
+                    push_ray(V.scene, r, alive, nq, flags);
+                    na += static_cast<uint32_t>(__popcll(__ballot(alive)));
+                    park_store(j, rng, L[0], thr[0], flags);
+                }
+            }
+            // ---- pixel_sum += sample, strictly in sample order (worker.rs:41-43): the passes in index order
+#pragma nounroll
+            for (int j = 0; j < NSUB; j++) {
+                const uint32_t* p = park + j * 64 + lane;
+                const float L = as_f(p[8 * QN]);
+                const bool primary_hit = (p[10 * QN] & kPoolPrimary) != 0u;
+                cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
+                add_samples_in_order<S>(acc, L, lane);
+            }
+            const RenderParams& A = params_view(KP);  // accumulation
+            if (A.chunked && ((s0 + S * NSUB) & (kSumChunk - 1u)) == 0u && s0 + S * NSUB <= s_end) chunk_flush(A, off, inpix && sub == 0, acc);
+        }
+        const RenderParams& E = params_view(KP);  // unit end
+        if (inpix && sub == 0) pixel_state_store(E, off, acc, cnt);
+        if (E.tile_cost && lane == 0) atomicAdd(E.tile_cost + tile_i, static_cast<unsigned long long>(__builtin_readcyclecounter() - t_unit));
+    }
+    const RenderParams& Z = params_view(KP);
+    if (lane == 0 && Z.segments && segs) atomicAdd(Z.segments, segs);
+}
+
 // ---- staged ("wavefront") evaluation of the path extension: MP_FLAG_WAVEFRONT --------------------------------------
 // The north star's formulation, kept beside the fused render_paths_kernel: the paths of a batch (a few tiles x a chunk of
 // samples, ~2 M paths) live in HBM as SoA streams (RNG state, ray, throughput, radiance, hit); per segment: a vertex kernel
@@ -2103,6 +2321,8 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     P.tile_cost = L.d_tile_cost;
     P.max_depth = L.max_depth;
     P.segments = L.d_segments;
+    P.pool = nullptr;
+    P.pool_stride = 0;
     P.lds_per_wave = lds_bytes_per_wave(L.scene.stack_cap);
     const uint32_t lds = P.lds_per_wave * 4;
     if (lds > 160 * 1024) { err = "scene too deep for the LDS traversal stacks"; return MP_ERR_UNSUPPORTED; }
@@ -2126,6 +2346,31 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     } while (0)
         const bool rgb = L.scene.materials_rgb != 0u;  // a coloured / textured material table: three channels
         if (rgb && L.chunked) { err = "coloured / textured materials are not combined with MP_FLAG_CHUNKED_SUM"; return MP_ERR_UNSUPPORTED; }
+        // pooled form (render_paths_pooled_kernel): plain TriangleBvh scenes with a grey table, at least two passes of 8 samples.
+        // By default for scenes whose traversal arrays exceed 1 MB -- there the 8-lane-group walk dominates and the longer queue
+        // pays (stand-in depth 8: 564 against 628 ms); on the teapot, where most paths end after one or two segments and ray
+        // generation and shading dominate, the one-pass kernel is faster (50.2 against 54.3 ms).  paths_pooled: 0 never, 1 auto,
+        // 2 always with two passes, 3 always with up to four.
+        const bool big_scene = (static_cast<uint64_t>(L.scene.inner_count) * 256u + static_cast<uint64_t>(L.scene.packet_count) * 384u) > (1u << 20);
+        const bool pooled = L.paths_pooled >= 2u || (L.paths_pooled == 1u && big_scene);
+        if (pooled && !rgb && L.scene.inst_count == 0u && L.max_depth >= 2 && nspp >= 16) {
+            const int nsub = (nspp >= 32 && L.paths_pooled != 2u) ? 4 : 2;
+            const uint32_t plds_wave = 8u * L.scene.stack_cap * 8u;  // the eight traversal stacks; the ray queue lives in the pool
+            P.lds_per_wave = plds_wave;
+            const uint32_t plds = plds_wave * 4u;
+            if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stacks"; return MP_ERR_UNSUPPORTED; }
+            const uint32_t pper_cu = plds ? std::max<uint32_t>(1, std::min<uint32_t>(8, (160u * 1024u) / plds)) : 8u;
+            const uint32_t pgrid = static_cast<uint32_t>(std::min<uint64_t>(want * 8, static_cast<uint64_t>(L.cu_count) * pper_cu));
+            P.pool_stride = pool_floats_per_wave(nsub);
+            const size_t bytes = static_cast<size_t>(pgrid) * 4u * P.pool_stride * sizeof(float);
+            rc = check(hipMallocAsync(reinterpret_cast<void**>(&P.pool), bytes, st), "hipMallocAsync(path pool)", err);
+            if (rc) return rc;
+            if (nsub == 4) hipLaunchKernelGGL(render_paths_pooled_kernel<4>, dim3(pgrid), dim3(256), plds, st, P);
+            else hipLaunchKernelGGL(render_paths_pooled_kernel<2>, dim3(pgrid), dim3(256), plds, st, P);
+            rc = check(hipGetLastError(), "render_paths_pooled_kernel launch", err);
+            (void)hipFreeAsync(P.pool, st);
+            return rc;
+        }
         if (S == 8) MP_LAUNCH_PATHS(8);
         else if (S == 4) MP_LAUNCH_PATHS(4);
         else if (S == 2) MP_LAUNCH_PATHS(2);

@@ -206,3 +206,66 @@ def test_coloured_and_checker_materials(ctx, oracle):
     torch.cuda.synchronize()
     got = img.cpu().numpy()
     assert np.array_equal(bits(got), bits(ogr)) and np.array_equal(got[..., 0], got[..., 1])
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_pooled_path_kernel_modes(oracle, teapot_oracle_bvh, mode):
+    """Round 3: the pooled form of the fused path kernel (several passes of 8 samples share one 8-lane-group walk over a per-wave ray
+    queue in global memory, the passes' path state parked beside it) against the one-pass kernel (mode 0): same operations per path,
+    same sample order -- the same bits and segment counts as the oracle, on an open scene (most paths end early: thin queues), an
+    interior scene (every path survives to max_depth), ragged progressive passes that start and end inside a batch, and the chunked
+    accumulation rule (a 256-sample chunk boundary never falls inside a batch)."""
+    import ctypes as C
+
+    import torch
+
+    from minipath_amd import scenes
+
+    c = mp.Context(0)
+    c.set_option("paths_pooled", mode)
+    teapot = mp.Scene(mp.TriangleBvh.with_obj(TEAPOT, c))
+    cam = mp.Camera.teapot_view()
+    for spp, depth, res, tile in ((40, 5, (256, 256), (64, 96, 128, 160)), (17, 3, (250, 130), (192, 64, 250, 128)), (70, 2, (256, 256), (96, 96, 128, 128))):
+        st = mp.RenderSettings(64, spp, res, seed=SEED, max_depth=depth)
+        fr = mp.FrameRenderer(teapot, cam, st, tiles=[mp.ScreenBlock(*tile)])
+        buf = fr.render()
+        torch.cuda.synchronize()
+        tw, th = tile[2] - tile[0], tile[3] - tile[1]
+        of, _, seg = teapot_oracle_bvh.render_tile_paths(oracle.build_sampler(oracle.teapot_camera(), *res), res[0], res[1], spp, SEED, depth, *tile)
+        assert np.array_equal(bits(buf[0, :th, :tw].cpu().numpy()), bits(of)), (mode, spp, depth)
+        assert int(fr.segments.item()) == seg
+        # ragged progressive passes: 13 + 9 + the rest start and end inside batches of 16 / 32 samples
+        fp = mp.FrameRenderer(teapot, cam, st, tiles=[mp.ScreenBlock(*tile)])
+        nxt, segs = 0, 0
+        for count in (13, 9, 0) if spp > 22 else (5, 0):
+            nxt = fp.render_pass(nxt, count)
+            segs += int(fp.segments.item())
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(fp.tile_buf[0, :th, :tw].cpu().numpy()), bits(of)) and segs == seg
+    # interior scene, whole frame, also under the chunked rule
+    pos, nrm, tex, tri = scenes.atrium(1, 0.05)
+    scene = mp.Scene(mp.TriangleBvh.build(pos, nrm, tex, tri, c))
+    orc = oracle.Bvh.build(pos, nrm, tex, tri)
+    oc = oracle.Camera()
+    oracle.lib().mpo_camera_default(C.byref(oc))
+    eye, at, fnum = scenes.ATRIUM_VIEW
+    oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(*eye), oracle.vec3(*at), oracle.vec3(0, 1, 0))
+    oc.f_number = fnum
+    res = (96, 64)
+    smp = oracle.build_sampler(oc, *res)
+    for spp, depth, chunked in ((32, 6, False), (300, 3, True)):
+        oracle.lib().mpo_set_chunked_sum(1 if chunked else 0)
+        try:
+            of, _, _, seg = orc.render_image_paths_mt(smp, res[0], res[1], spp, 11, depth, 32, 8)
+        finally:
+            oracle.lib().mpo_set_chunked_sum(0)
+        fr = mp.FrameRenderer(scene, scenes.atrium_camera(), mp.RenderSettings(32, spp, res, seed=11, max_depth=depth, chunked_sum=chunked))
+        if chunked:
+            nxt = fr.render_pass(0, 100); nxt = fr.render_pass(nxt, 157); fr.render_pass(nxt)
+        else:
+            fr.render()
+        img, _ = fr.untile()
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(img.cpu().numpy()), bits(of)), (mode, spp, chunked, int(np.sum(bits(img.cpu().numpy()) != bits(of))))
+        if not chunked:
+            assert int(fr.segments.item()) == seg

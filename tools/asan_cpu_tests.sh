@@ -9,5 +9,5 @@ RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | he
 export MINIPATH_HIP_SO=$PWD/minipath_amd/csrc/libminipath_hip_asan.so
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=1:halt_on_error=1
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
-LD_PRELOAD=$RT python -m pytest tests/test_host_cpu.py tests/test_golden_cpu.py tests/test_distributed_cpu.py tests/test_io_cpu.py -x -q -m "not gpu" \
+LD_PRELOAD=$RT python -m pytest tests/test_host_cpu.py tests/test_device_tree_cpu.py tests/test_golden_cpu.py tests/test_distributed_cpu.py tests/test_io_cpu.py -x -q -m "not gpu" \
     --deselect tests/test_host_cpu.py::test_no_exception_crosses_the_abi "$@"

@@ -49,6 +49,7 @@ def run(cases, seed, ctx=None):
         s_opt = int(rng.choice([0, 0, 1, 4, 8, 16, 32, 64]))
         ctx.set_option("packet_samples_in_flight", s_opt)
         ctx.set_option("packet_stack_registers", int(rng.choice([64, 64, 3, 9])))
+        ctx.set_option("paths_pooled", int(rng.choice([0, 1, 2, 3, 3])))   # one pass per walk / pooled passes of the fused path kernel
         chunked = bool(rng.random() < 0.25)
         if chunked:
             spp = int(rng.choice([spp, 300, 513]))
@@ -112,6 +113,7 @@ def run(cases, seed, ctx=None):
                   f"{int(np.sum(bits(img.cpu().numpy()) != bits(of)))} f32 values differ")
     ctx.set_option("packet_samples_in_flight", 0)
     ctx.set_option("packet_stack_registers", 64)
+    ctx.set_option("paths_pooled", 1)
     return bad
 
 
