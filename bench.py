@@ -323,7 +323,14 @@ def main():
     m = measure(scene, cam, st, args.steps, args.warmup, args.balance)
     if args.depth == 0:
         assert m["seg_total"] == total_samples, (m["seg_total"], total_samples)
-    kname = "render_paths_kernel" if args.depth > 0 else ("render_tiles_packet_kernel" if args.traversal == "packets" else "render_tiles_kernel")
+    def paths_kernel(scene_, spp_, depth_):
+        """The fused path kernel the launcher picks (kernels.hip, launch_render_tiles): the pooled form for scenes whose traversal
+        arrays exceed 1 MB, at least two passes of 8 samples and two segments; otherwise one pass per walk."""
+        i = scene_.object.info()
+        big = i.inner_count * 256 + i.packet_count * 384 > (1 << 20)
+        return "render_paths_pooled_kernel" if (big and depth_ >= 2 and spp_ >= 16) else "render_paths_kernel"
+
+    kname = paths_kernel(scene, args.spp, args.depth) if args.depth > 0 else ("render_tiles_packet_kernel" if args.traversal == "packets" else "render_tiles_kernel")
     key = workload_key(scene_name, args.width, args.height, args.spp, args.tile, args.depth, args.traversal)
     cu = ctx.cu_count
 
@@ -337,7 +344,7 @@ def main():
             "value": m2["seg_total"] * steps / m2["elapsed"] / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup,
             "ms_per_step": m2["elapsed"] / steps * 1e3, "samples_per_s": samples * steps / m2["elapsed"],
             "segments_per_sample": m2["seg_total"] / samples,
-            "roofline": roofline("render_paths_kernel" if depth > 0 else "render_tiles_packet_kernel", m2,
+            "roofline": roofline(paths_kernel(scene_, spp, depth) if depth > 0 else "render_tiles_packet_kernel", m2,
                                  B_RAY_BOUNCE if depth > 0 else B_RAY_DEPTH1,
                                  workload_key(name_, args.width, args.height, spp, args.tile, depth, "packets"), cu),
         }

@@ -1653,12 +1653,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_POOL_WPE
         stack = reinterpret_cast<uint2*>(smem + static_cast<size_t>(wave) * P0.lds_per_wave);
     }
     auto park_store = [&](int j, const Rng& rng, float L, float thr, uint32_t flags) {
+        // streamed (non-temporal): 200 MB of parked state per launch must not push the scene out of the L2
         uint32_t* p = park + j * 64 + lane;
-        p[0 * QN] = static_cast<uint32_t>(rng.s0); p[1 * QN] = static_cast<uint32_t>(rng.s0 >> 32);
-        p[2 * QN] = static_cast<uint32_t>(rng.s1); p[3 * QN] = static_cast<uint32_t>(rng.s1 >> 32);
-        p[4 * QN] = static_cast<uint32_t>(rng.s2); p[5 * QN] = static_cast<uint32_t>(rng.s2 >> 32);
-        p[6 * QN] = static_cast<uint32_t>(rng.s3); p[7 * QN] = static_cast<uint32_t>(rng.s3 >> 32);
-        p[8 * QN] = as_u(L); p[9 * QN] = as_u(thr); p[10 * QN] = flags;
+        __builtin_nontemporal_store(static_cast<uint32_t>(rng.s0), p + 0 * QN); __builtin_nontemporal_store(static_cast<uint32_t>(rng.s0 >> 32), p + 1 * QN);
+        __builtin_nontemporal_store(static_cast<uint32_t>(rng.s1), p + 2 * QN); __builtin_nontemporal_store(static_cast<uint32_t>(rng.s1 >> 32), p + 3 * QN);
+        __builtin_nontemporal_store(static_cast<uint32_t>(rng.s2), p + 4 * QN); __builtin_nontemporal_store(static_cast<uint32_t>(rng.s2 >> 32), p + 5 * QN);
+        __builtin_nontemporal_store(static_cast<uint32_t>(rng.s3), p + 6 * QN); __builtin_nontemporal_store(static_cast<uint32_t>(rng.s3 >> 32), p + 7 * QN);
+        __builtin_nontemporal_store(as_u(L), p + 8 * QN); __builtin_nontemporal_store(as_u(thr), p + 9 * QN); __builtin_nontemporal_store(flags, p + 10 * QN);
     };
     // bounce ray of a path that is still alive: into the queue (compacted over the lanes whose ray can reach the scene at all)
     auto push_ray = [&](const DevScene& sc, const Ray& r, bool alive, uint32_t& nq, uint32_t& flags) {
@@ -1746,13 +1747,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_POOL_WPE
     #pragma nounroll
             for (int j = 0; j < NSUB; j++) {
                     const uint32_t* p = park + j * 64 + lane;
-                    uint32_t flags = p[10 * QN];
+                    uint32_t flags = __builtin_nontemporal_load(p + 10 * QN);
                     bool alive = (flags & kPoolAlive) != 0u;
                     if (__ballot(alive) == 0) continue;  // the whole pass is finished: its parked L / flags stay as they are
                     Rng rng;
-                    rng.s0 = p[0 * QN] | (static_cast<uint64_t>(p[1 * QN]) << 32); rng.s1 = p[2 * QN] | (static_cast<uint64_t>(p[3 * QN]) << 32);
-                    rng.s2 = p[4 * QN] | (static_cast<uint64_t>(p[5 * QN]) << 32); rng.s3 = p[6 * QN] | (static_cast<uint64_t>(p[7 * QN]) << 32);
-                    float L[1] = {as_f(p[8 * QN])}, thr[1] = {as_f(p[9 * QN])};
+                    auto ld = [&](int row) { return static_cast<uint64_t>(__builtin_nontemporal_load(p + row * QN)); };
+                    rng.s0 = ld(0) | (ld(1) << 32); rng.s1 = ld(2) | (ld(3) << 32);
+                    rng.s2 = ld(4) | (ld(5) << 32); rng.s3 = ld(6) | (ld(7) << 32);
+                    float L[1] = {as_f(static_cast<uint32_t>(ld(8)))}, thr[1] = {as_f(static_cast<uint32_t>(ld(9)))};
                     bool primary_hit = (flags & kPoolPrimary) != 0u;
                     Ray r;
                     r.ox = r.oy = r.oz = r.dx = r.dy = r.dz = r.ix = r.iy = r.iz = 0.0f;

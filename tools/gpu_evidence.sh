@@ -21,9 +21,9 @@ if [ "$1" = "collect" ]; then
   echo "profiles/r03_* written"; exit 0
 fi
 bash tools/gpu_counters.sh atrium256 render_tiles_packet_kernel
-bash tools/gpu_counters.sh atrium_d8 render_paths_kernel --spp 64 --depth 8
+bash tools/gpu_counters.sh atrium_d8 render_paths --spp 64 --depth 8
 bash tools/gpu_counters.sh teapot256 render_tiles_packet_kernel --scene teapot
-bash tools/gpu_counters.sh teapot_d8 render_paths_kernel --scene teapot --depth 8
+bash tools/gpu_counters.sh teapot_d8 render_paths --scene teapot --depth 8
 collect_counters   # on the box too: the default bench line below then carries the counter-derived figures of THIS build
 python3 bench.py > gpurun_out/bench_r03_final.log 2>&1
 grep '^{' gpurun_out/bench_r03_final.log > gpurun_out/bench_r03_final.json
