@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Differential test of mp_trace_rays (8-lane-group traversal) against the oracle on many random rays per scene, incl. zero / -0 /
-axis-parallel direction components and origins inside the scene.  usage: fuzz_trace.py [rays_per_scene] [seed]"""
+axis-parallel direction components and origins inside the scene (the atrium scene exercises the wide device tree).  usage: fuzz_trace.py [rays_per_scene] [seed]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,10 +15,15 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ctx = mp.Context(0)
 bad = 0
-for si, name in enumerate(("soup_300", "grid_40", "sphere_24", "flat_plane", "soup_5000", "teapot")):
+for si, name in enumerate(("soup_300", "grid_40", "sphere_24", "flat_plane", "soup_5000", "teapot", "atrium")):
     if name == "teapot":
         scene = mp.TriangleBvh.with_obj(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "teapot.obj"), ctx)
         ob = po.Bvh.from_obj(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "teapot.obj"))
+    elif name == "atrium":  # the Sponza stand-in at a tenth of its detail: a tree whose thin top nodes the WIDE device tree absorbs
+        from minipath_amd import scenes
+        pos, nrm, tex, tri = scenes.atrium(1, 0.1)
+        scene = mp.TriangleBvh.build(pos, nrm, tex, tri, ctx); ob = po.Bvh.build(pos, nrm, tex, tri)
+        assert scene.device_tree()[3] > 0
     else:
         pos, nrm, tex, tri = meshes.make(name)
         scene = mp.TriangleBvh.build(pos, nrm, tex, tri, ctx); ob = po.Bvh.build(pos, nrm, tex, tri)
