@@ -79,6 +79,7 @@ struct mp_ctx {
     std::atomic<uint32_t> packet_samples{0};  // 0 = chosen by the launcher
     std::atomic<uint32_t> rays_per_lane{1};   // packet kernel: 1 = 64-ray walks, 2 = 128-ray walks (two rays per lane)
     std::atomic<uint32_t> blocks_per_cu{0};   // 0 = as many as fit (diagnostic knob: resident workgroups per CU)
+    std::atomic<uint32_t> mask_cache{1};      // packet kernel: per-unit mask cache of the packet-level child rejection
     std::atomic<uint32_t> paths_pooled{1};    // path extension: 0 = render_paths_kernel, 1 = auto, 2 / 3 = always pooled (RenderLaunch::paths_pooled)
     uint32_t* take_counter() {  // one set of work-queue heads per launch in flight
         return d_counters + static_cast<size_t>(next_counter.fetch_add(1, std::memory_order_relaxed) % kCounters) * kWorkQueues * kWorkQueueStride;
@@ -486,6 +487,7 @@ int render_tiles_device(mp_ctx* ctx, const mp_scene* scene, const mp_camera_samp
     L.packet_samples = ctx->packet_samples.load();
     L.rays_per_lane = ctx->rays_per_lane.load();
     L.paths_pooled = ctx->paths_pooled.load();
+    L.mask_cache = ctx->mask_cache.load();
     L.sampler = sampler;
     L.width = st.width;
     L.height = st.height;
@@ -570,6 +572,11 @@ int mp_ctx_set_option(mp_ctx* ctx, const char* key, int value) {
     if (std::strcmp(key, "packet_stack_registers") == 0) {
         if (value < 1 || value > 64) return fail(MP_ERR_INVALID, "packet_stack_registers must be in 1..64");
         ctx->packet_stack_regs.store(static_cast<uint32_t>(value));
+        return MP_OK;
+    }
+    if (std::strcmp(key, "packet_mask_cache") == 0) {
+        if (value < 0 || value > 2) return fail(MP_ERR_INVALID, "packet_mask_cache must be 0 (off), 1 (scenes whose traversal arrays exceed 1 MB) or 2 (always)");
+        ctx->mask_cache.store(static_cast<uint32_t>(value));
         return MP_OK;
     }
     if (std::strcmp(key, "paths_pooled") == 0) {

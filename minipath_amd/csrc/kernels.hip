@@ -821,6 +821,130 @@ struct HybridStack {
 
 __device__ __forceinline__ uint32_t uniform_u(float f) { return __builtin_amdgcn_readfirstlane(as_u(f)); }
 
+// ---- packet-level child rejection with a per-unit mask cache (round 3) ----------------------------------------------------------
+// Counted on the metric's frame (tools/sim_collapse.py --packet-studies; profiles/r03_notes.md): a 64-ray camera packet tests 110
+// child boxes per pass and pushes 19; for 90 of the 91 others NO ray of the packet can pass, and a conservative test on bounds of
+// the packet -- componentwise min / max of the origins and inverse directions -- proves it.  Evaluating that test per node visit
+// (lane j = child j, the records through a vector load) was built first and ran slower than it saved (profiles/r03_notes.md).
+// What pays is doing it ONCE PER WORK UNIT: a unit shoots 8-16 passes through the same 2-4 pixels, and one set of bounds B that
+// contains every pass's rays gives one 8-bit "children that may be hit" mask per node, cached in LDS (the packet kernel uses no
+// other LDS).  A pass computes its own bounds P (12 wave reductions), and while P lies inside B and the sign pattern is the
+// same, a node visit costs one LDS lookup and the exact per-ray slab tests of the surviving children only.  B starts as the first
+// pass's P widened by half its extent; a pass that does not fit widens B and clears the cache.
+// Why skipping a child whose bit is clear is exact.  Only in the sign-specialised walks (OCT >= 0: every active ray has finite
+// inverse directions of one sign pattern) and only if every active origin and inverse component is finite.  Axis with inv > 0
+// (aabb.rs:257-271 gives lo = fl(fl(bmin - o) * inv), hi = fl(fl(bmax - o) * inv)): with omax >= o for every ray,
+// y = fl(bmin - omax) <= fl(bmin - o) (IEEE subtraction is monotone), so lo >= fl(y * inv) (multiplication by a positive number is
+// monotone) >= min(fl(y * imin), fl(y * imax)) =: L (x -> fl(y * x) is monotone on [imin, imax]: its minimum sits at an end);
+// likewise hi <= max(fl(z * imin), fl(z * imax)) =: U with z = fl(bmax - omin).  Axis with inv < 0: lo comes from bmax and products
+// decrease with the first factor: L from z, U from y.  Every ray's t1 = max(lo.x, 0, lo.y, lo.z) >= T1 = max(L.x, L.y, L.z, 0) and
+// its t2 = min(hi.x, limit, hi.y, hi.z) <= T2 = min(U.x, U.y, U.z); T1 > T2 therefore means t1 > t2 for every ray whose origin and
+// inverse direction lie in B: the reference pushes the child for none of them (ray_bvh_intersection.rs:158).  No NaN can arise: all
+// inputs are finite, inv is never 0, and B's inverse bounds keep the sign of the pattern.
+#ifndef MP_MCACHE_PAD
+#define MP_MCACHE_PAD 0.5f  // widening of the unit's bounds on either side, in extents of the pass that sets them (A/B: profiles/r03_notes.md)
+#endif
+constexpr int kMaskCacheEntries = 512;                      // direct-mapped: node index & 511 ; entry = node << 8 | mask
+constexpr int kMaskCacheDwords = 16 + kMaskCacheEntries;    // header: B (12 floats), [12] = sign pattern | 0x100 when valid (0xFFFFFFFF: none)
+struct MaskCache {
+    uint32_t* lds;  // this wave's header + entries, or nullptr: no packet-level rejection
+};
+// Wave-wide minima of six values and maxima of six values at once (every lane takes part; inactive rays hold the neutral element):
+// four DPP steps inside each row of 16, row_bcast15 / row_bcast31 across the rows, the totals end in lane 63.  The twelve
+// independent chains are interleaved step by step, so no instruction reads a register the previous two instructions wrote (the
+// DPP read-after-VALU-write hazard needs two wait states) and no s_nop is spent.
+#define MP_DPP_STEP12(CTRL)                                                                                             \
+    "v_min_f32_dpp %0, %0, %0 " CTRL "\n\tv_min_f32_dpp %1, %1, %1 " CTRL "\n\tv_min_f32_dpp %2, %2, %2 " CTRL "\n\t"         \
+    "v_min_f32_dpp %3, %3, %3 " CTRL "\n\tv_min_f32_dpp %4, %4, %4 " CTRL "\n\tv_min_f32_dpp %5, %5, %5 " CTRL "\n\t"         \
+    "v_max_f32_dpp %6, %6, %6 " CTRL "\n\tv_max_f32_dpp %7, %7, %7 " CTRL "\n\tv_max_f32_dpp %8, %8, %8 " CTRL "\n\t"         \
+    "v_max_f32_dpp %9, %9, %9 " CTRL "\n\tv_max_f32_dpp %10, %10, %10 " CTRL "\n\tv_max_f32_dpp %11, %11, %11 " CTRL "\n\t"
+__device__ __forceinline__ void wave_min6_max6(float (&mn)[6], float (&mx)[6]) {
+    asm volatile("s_nop 1\n\t"  // the operands may come straight out of VALU instructions
+                 MP_DPP_STEP12("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 MP_DPP_STEP12("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 MP_DPP_STEP12("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 MP_DPP_STEP12("row_mirror row_mask:0xf bank_mask:0xf")
+                 MP_DPP_STEP12("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 MP_DPP_STEP12("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(mn[0]), "+v"(mn[1]), "+v"(mn[2]), "+v"(mn[3]), "+v"(mn[4]), "+v"(mn[5]), "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]),
+                   "+v"(mx[3]), "+v"(mx[4]), "+v"(mx[5]));
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        mn[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mn[k]), 63));
+        mx[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx[k]), 63));
+    }
+}
+// Called once per pass, before a sign-specialised walk with pattern `oct`: makes the cache's bounds B contain this pass's rays
+// (widening B and clearing the masks if they do not).  Returns false when the pass cannot use the cache (a non-finite component).
+__device__ __forceinline__ bool mask_cache_begin_pass(const MaskCache& mc, const Ray& r, bool active, uint32_t oct) {
+    const int lane = static_cast<int>(threadIdx.x) & 63;
+    const bool fin = fabsf(r.ox) < INFINITY && fabsf(r.oy) < INFINITY && fabsf(r.oz) < INFINITY && fabsf(r.ix) < INFINITY &&
+                     fabsf(r.iy) < INFINITY && fabsf(r.iz) < INFINITY;
+    if (__ballot(active && !fin) != 0) return false;
+    const float val[6] = {r.ox, r.oy, r.oz, r.ix, r.iy, r.iz};
+    float pmin[6], pmax[6];  // wave-uniform after the reduction
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        pmin[k] = active ? val[k] : INFINITY;
+        pmax[k] = active ? val[k] : -INFINITY;
+    }
+    wave_min6_max6(pmin, pmax);
+    float* hdr = reinterpret_cast<float*>(mc.lds);  // omin[3], omax[3], imin[3], imax[3]
+    const uint32_t state = __builtin_amdgcn_readfirstlane(mc.lds[12]);
+    bool inside = state == (oct | 0x100u);
+    if (inside) {  // P inside B ?
+        bool viol = false;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            viol = viol || pmin[k] < hdr[k] || pmax[k] > hdr[3 + k] || pmin[3 + k] < hdr[6 + k] || pmax[3 + k] > hdr[9 + k];
+        inside = __ballot(viol) == 0;
+    }
+    if (!inside) {
+        // new bounds: this pass's, united with the old ones when they belong to the same sign pattern, widened by half the extent
+        // (an inverse-direction bound never crosses zero: the sign pattern is part of the masks' meaning)
+        const bool keep = state == (oct | 0x100u);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            float lo = pmin[k], hi = pmax[k];
+            if (keep) { lo = fminf(lo, hdr[k < 3 ? k : 3 + k]); hi = fmaxf(hi, hdr[k < 3 ? 3 + k : 6 + k]); }
+            const float pad = (hi - lo) * MP_MCACHE_PAD;
+            float wlo = lo - pad, whi = hi + pad;
+            if (k >= 3) {  // same sign as the pass's inverse directions (all of one sign, finite, non-zero)
+                if ((wlo < 0.0f) != (lo < 0.0f) || wlo == 0.0f) wlo = lo;
+                if ((whi < 0.0f) != (hi < 0.0f) || whi == 0.0f) whi = hi;
+            }
+            if (!(fabsf(wlo) < INFINITY)) wlo = lo;
+            if (!(fabsf(whi) < INFINITY)) whi = hi;
+            pmin[k] = wlo; pmax[k] = whi;
+        }
+        wave_lds_sync();  // the reads above before the header is rewritten
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { hdr[k] = pmin[k]; hdr[3 + k] = pmax[k]; hdr[6 + k] = pmin[3 + k]; hdr[9 + k] = pmax[3 + k]; }
+            mc.lds[12] = oct | 0x100u;
+        }
+#pragma unroll
+        for (int i = 0; i < kMaskCacheEntries / 64; i++) mc.lds[16 + i * 64 + lane] = 0xFFFFFFFFu;  // no node has this tag
+        wave_lds_sync();
+    }
+    return true;
+}
+// lane j (0..7): can any ray with origin / inverse direction inside the bounds `b` (omin[3], omax[3], imin[3], imax[3]) pass child
+// j's box {bmn, bmx}?  (see above)
+template <int OCT>
+__device__ __forceinline__ bool bounds_may_hit(const float* b, const float bmn[3], const float bmx[3]) {
+    float L[3], U[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float y = bmn[k] - b[3 + k], z = bmx[k] - b[k];
+        const float lo_src = ((OCT >> k) & 1) ? z : y, hi_src = ((OCT >> k) & 1) ? y : z;
+        L[k] = fminf(lo_src * b[6 + k], lo_src * b[9 + k]);
+        U[k] = fmaxf(hi_src * b[6 + k], hi_src * b[9 + k]);
+    }
+    const float t1 = fmaxf(fmaxf(L[0], 0.0f), fmaxf(L[1], L[2])), t2 = fminf(U[0], fminf(U[1], U[2]));
+    return !(t1 > t2);
+}
+
 // MODE 1: every active ray has finite inverse directions (no 0*inf, so the NaN patches of aabb.rs:262-267 are dead code).
 // MODE 2: literal aabb.rs:254-284.
 //
@@ -833,7 +957,8 @@ __device__ __forceinline__ uint32_t uniform_u(float f) { return __builtin_amdgcn
 // branch on VCC; det's magnitude guard is a v_cndmask, the three sign tests one minNum chain; loops are single-exit pair loops
 // with a scalar countdown; pushes are v_writelane; staleness is a low-water mark instead of a 64-bit mask.
 template <int MODE, int OCT, class Stack>
-__device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
+__device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit,
+                                                  uint32_t* mcache = nullptr) {
     constexpr bool PATCH_NAN = MODE == 2;
     // MODE 2 walks the literal reference tree, MODE 1 the wide tree (thin nodes absorbed into their parents: bit-identical hits
     // for rays with finite inverse directions, device_tree.cpp)
@@ -865,9 +990,6 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
             // = index of the node's last real child + 1.  Two SGPR sets alternate: B is fetched while A is tested.
             const uint32_t node = link >> 6;
             kfp nd = nodes + static_cast<size_t>(node) * 64;
-            float a0 = nd[0], a1 = nd[1], a2 = nd[2], a3 = nd[3], a4 = nd[4], a5 = nd[5], a6 = nd[6];
-            const uint32_t nchild = uniform_u(nd[7]);
-            uint32_t slot = node * 8u;
             auto child = [&](const float b0, const float b1, const float b2, const float b3, const float b4, const float b5,
                              const float blink, const uint32_t cslot) {
                 const uint32_t cl = uniform_u(blink);
@@ -910,6 +1032,48 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                     sp++;
                 }
             };
+            if (OCT >= 0 && mcache != nullptr) {
+                // per-unit mask cache (see MaskCache): which children can ANY ray inside the unit's bounds pass?
+                const uint32_t cslot = 16u + (node & static_cast<uint32_t>(kMaskCacheEntries - 1));
+                const uint32_t e = __builtin_amdgcn_readfirstlane(mcache[cslot]);
+                uint32_t todo;
+                if ((e >> 8) == node) {
+                    todo = e & 0xFFu;
+                } else {  // first visit of this node under the current bounds: lane j = child j, records through one vector load pair
+                    const int cj = static_cast<int>(threadIdx.x) & 7;
+                    bool keep = false;
+                    if ((threadIdx.x & 63u) < 8u) {
+                        const float4* rec = reinterpret_cast<const float4*>(sc.nodes_aos) + (static_cast<size_t>(node) * 8 + static_cast<size_t>(cj)) * 2;
+                        const float4 c0 = rec[0], c1 = rec[1];  // {min.xyz, max.x} {max.yz, link, n}
+                        const float bmn[3] = {c0.x, c0.y, c0.z}, bmx[3] = {c0.w, c1.x, c1.y};
+                        keep = as_u(c1.z) != MP_LINK_NULL && bounds_may_hit<OCT>(reinterpret_cast<const float*>(mcache), bmn, bmx);
+                    }
+                    todo = static_cast<uint32_t>(__ballot(keep)) & 0xFFu;
+                    if ((threadIdx.x & 63u) == 0u) mcache[cslot] = (node << 8) | todo;
+                }
+                // the surviving children, ascending, through the scalar unit: the next survivor's record is fetched while this one is tested
+                if (todo != 0u) {
+                    uint32_t c = static_cast<uint32_t>(__builtin_ctz(todo));
+                    todo &= todo - 1u;
+                    kfp rc = nd + c * 8u;
+                    float a0 = rc[0], a1 = rc[1], a2 = rc[2], a3 = rc[3], a4 = rc[4], a5 = rc[5], a6 = rc[6];
+                    while (todo != 0u) {
+                        const uint32_t cn = static_cast<uint32_t>(__builtin_ctz(todo));
+                        todo &= todo - 1u;
+                        kfp rn = nd + cn * 8u;
+                        const float b0 = rn[0], b1 = rn[1], b2 = rn[2], b3 = rn[3], b4 = rn[4], b5 = rn[5], b6 = rn[6];
+                        child(a0, a1, a2, a3, a4, a5, a6, node * 8u + c);
+                        a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6;
+                        c = cn;
+                    }
+                    child(a0, a1, a2, a3, a4, a5, a6, node * 8u + c);
+                }
+                st.sync(sp);
+                continue;
+            }
+            float a0 = nd[0], a1 = nd[1], a2 = nd[2], a3 = nd[3], a4 = nd[4], a5 = nd[5], a6 = nd[6];
+            const uint32_t nchild = uniform_u(nd[7]);
+            uint32_t slot = node * 8u;
             for (uint32_t p = nchild >> 1; p > 0; p--) {
                 const float b0 = nd[8], b1 = nd[9], b2 = nd[10], b3 = nd[11], b4 = nd[12], b5 = nd[13], b6 = nd[14];
                 child(a0, a1, a2, a3, a4, a5, a6, slot);
@@ -980,7 +1144,8 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
 
 // OCTANTS: also instantiate the eight sign-specialised walks (the production kernels; the rest keep the generic slab).
 template <bool OCTANTS, class Stack>
-__device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
+__device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit,
+                                             const MaskCache& mc = MaskCache{nullptr}) {
     const bool slow = active && (fabsf(r.ix) == INFINITY || fabsf(r.iy) == INFINITY || fabsf(r.iz) == INFINITY);
     if (__ballot(slow) != 0) {
         trace_packet_impl<2, -1>(sc, r, active, st, hit);
@@ -990,15 +1155,17 @@ __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, b
         const uint64_t am = __ballot(active);
         const uint64_t nx = __ballot(active && r.ix < 0.0f), ny = __ballot(active && r.iy < 0.0f), nz = __ballot(active && r.iz < 0.0f);
         if ((nx == 0 || nx == am) && (ny == 0 || ny == am) && (nz == 0 || nz == am)) {
-            switch ((nx ? 1 : 0) | (ny ? 2 : 0) | (nz ? 4 : 0)) {
-                case 0: trace_packet_impl<1, 0>(sc, r, active, st, hit); return;
-                case 1: trace_packet_impl<1, 1>(sc, r, active, st, hit); return;
-                case 2: trace_packet_impl<1, 2>(sc, r, active, st, hit); return;
-                case 3: trace_packet_impl<1, 3>(sc, r, active, st, hit); return;
-                case 4: trace_packet_impl<1, 4>(sc, r, active, st, hit); return;
-                case 5: trace_packet_impl<1, 5>(sc, r, active, st, hit); return;
-                case 6: trace_packet_impl<1, 6>(sc, r, active, st, hit); return;
-                default: trace_packet_impl<1, 7>(sc, r, active, st, hit); return;
+            const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
+            uint32_t* mcache = (mc.lds != nullptr && mask_cache_begin_pass(mc, r, active, oct)) ? mc.lds : nullptr;
+            switch (oct) {
+                case 0: trace_packet_impl<1, 0>(sc, r, active, st, hit, mcache); return;
+                case 1: trace_packet_impl<1, 1>(sc, r, active, st, hit, mcache); return;
+                case 2: trace_packet_impl<1, 2>(sc, r, active, st, hit, mcache); return;
+                case 3: trace_packet_impl<1, 3>(sc, r, active, st, hit, mcache); return;
+                case 4: trace_packet_impl<1, 4>(sc, r, active, st, hit, mcache); return;
+                case 5: trace_packet_impl<1, 5>(sc, r, active, st, hit, mcache); return;
+                case 6: trace_packet_impl<1, 6>(sc, r, active, st, hit, mcache); return;
+                default: trace_packet_impl<1, 7>(sc, r, active, st, hit, mcache); return;
             }
         }
     }
@@ -1259,7 +1426,7 @@ __device__ __forceinline__ void add_samples_in_order(float& acc, float c, int la
 // accumulated strictly in sample order (worker.rs:41-43), redundantly by every lane of the pixel (add_samples_in_order).
 // WPE = waves per SIMD the register allocation is held to: 8 (64 VGPRs) hides the scalar-cache misses of scenes that
 // outgrow it, 7 (72 VGPRs) schedules slightly better when the scene stays cache resident (profiles/r01_notes.md).
-template <int S, bool LDS_STACK, int WPE, bool OBJ = false>
+template <int S, bool LDS_STACK, int WPE, bool OBJ = false, bool MCACHE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void render_tiles_packet_kernel(RenderParams) {
     extern __shared__ __align__(16) unsigned char smem[];
     MP_KERNEL_PARAMS;
@@ -1269,6 +1436,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     const int pix = lane / S, sub = lane % S;
     const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1));
     uint32_t qstate = blockIdx.x % kWorkQueues;
+    // per-unit mask cache of the packet-level child rejection (MaskCache): this wave's header + entries in LDS
+    MaskCache mc{nullptr};
+    if (MCACHE) mc.lds = reinterpret_cast<uint32_t*>(smem) + static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6)) * kMaskCacheDwords;
     for (;;) {
         const RenderParams& P = params_view(KP);  // unit setup
         const uint32_t ts = P.tile_size;
@@ -1285,6 +1455,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
         const size_t off = (static_cast<size_t>(tile_i) * ts * ts + static_cast<size_t>(py - T.min_y) * ts + (px - T.min_x)) * 4;
         float acc, cnt;  // pixel_sum (r=g=b) and alpha (worker.rs:40)
         pixel_state_load(P, off, inpix, sub == 0, acc, cnt);
+        if (MCACHE) {  // a new unit: other pixels, other bounds
+            if (lane == 0) mc.lds[12] = 0xFFFFFFFFu;
+            wave_lds_sync();
+        }
         // passes are aligned to multiples of S in the absolute sample index, so that a chunk boundary (MP_FLAG_CHUNKED_SUM) never
         // falls inside a pass; lanes outside [s_begin, s_end) add +0.0, which is exact
         const uint32_t s_begin = P.s_begin, s_end = P.s_end;
@@ -1319,7 +1493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                             trace_packet<false>(W.scene, r, go, st, h);
                         } else {
                             RegStack st(lds, lane);
-                            trace_packet<(S >= 8 && S <= 32)>(W.scene, r, go, st, h);
+                            trace_packet<(S >= 8 && S <= 32)>(W.scene, r, go, st, h, mc);
                         }
                     }
                 }
@@ -2417,6 +2591,19 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         if (lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<SV, true, W>), dim3(grid), dim3(256), plds, st, P); \
         else hipLaunchKernelGGL((render_tiles_packet_kernel<SV, false, W>), dim3(grid), dim3(256), 0, st, P);           \
     } while (0)
+    // per-unit mask cache of the packet-level child rejection: units of at least four passes, stack in registers, node indices
+    // that fit the cache tag; 2 112 bytes of LDS per wave
+#ifndef MP_MCACHE_WPE
+#define MP_MCACHE_WPE 8
+#endif
+    // (big scenes only: a teapot packet visits 2.5 nodes per pass, fewer than the per-pass bounds cost -- 12.3 against 11.8 ms)
+    const bool mcache = (L.mask_cache == 2u || (L.mask_cache == 1u && big)) && !lds_stack && !obj && (S == 16 || S == 32) && nspp >= 4u * static_cast<uint32_t>(S) && L.scene.inner_count < (1u << 24);
+    if (mcache) {
+        const uint32_t clds = 4u * kMaskCacheDwords * 4u;
+        if (S == 32) hipLaunchKernelGGL((render_tiles_packet_kernel<32, false, MP_MCACHE_WPE, false, true>), dim3(grid), dim3(256), clds, st, P);
+        else hipLaunchKernelGGL((render_tiles_packet_kernel<16, false, MP_MCACHE_WPE, false, true>), dim3(grid), dim3(256), clds, st, P);
+        return check(hipGetLastError(), "render_tiles_packet_kernel launch", err);
+    }
     if (obj) {
         if (S == 16 && lds_stack) hipLaunchKernelGGL((render_tiles_packet_kernel<16, true, 6, true>), dim3(grid), dim3(256), plds, st, P);
         else if (S == 16) hipLaunchKernelGGL((render_tiles_packet_kernel<16, false, 6, true>), dim3(grid), dim3(256), 0, st, P);

@@ -269,3 +269,52 @@ def test_pooled_path_kernel_modes(oracle, teapot_oracle_bvh, mode):
         assert np.array_equal(bits(img.cpu().numpy()), bits(of)), (mode, spp, chunked, int(np.sum(bits(img.cpu().numpy()) != bits(of))))
         if not chunked:
             assert int(fr.segments.item()) == seg
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+def test_packet_mask_cache(oracle, teapot_oracle_bvh, mode):
+    """Round 3: the packet walk's per-unit mask cache (children that NO ray inside the bounds of the work unit's rays can hit are
+    skipped without their per-ray slab tests; bounds widened and masks rebuilt when a pass does not fit).  Exact by interval
+    arithmetic on monotone IEEE operations; here: frames with units of 4 to 16 passes, 16 and 32 samples in flight, a pinhole and a
+    wide lens (bounds of very different extent), a view along an axis (zero direction components: those passes take the literal
+    walk, the others the cache), ragged progressive passes, equal to the oracle bit for bit with the cache forced on and off."""
+    import ctypes as C
+
+    import torch
+
+    from minipath_amd import scenes
+
+    c = mp.Context(0)
+    c.set_option("packet_mask_cache", mode)
+    teapot = mp.Scene(mp.TriangleBvh.with_obj(TEAPOT, c))
+    res = (96, 64)
+    for fnum, spp, sflight in ((4.8, 64, 16), (1e9, 128, 32), (0.7, 70, 16)):
+        c.set_option("packet_samples_in_flight", sflight)
+        cam = mp.Camera.teapot_view().f_number(fnum)
+        oc = oracle.teapot_camera()
+        oc.f_number = fnum
+        of, ou8, _, seg, _ = teapot_oracle_bvh.render_image_mt(oracle.build_sampler(oc, *res), res[0], res[1], spp, SEED, 32, 8)
+        fr = mp.FrameRenderer(teapot, cam, mp.RenderSettings(32, spp, res, seed=SEED))
+        fr.render()
+        img, u8 = fr.untile()
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(img.cpu().numpy()), bits(of)), (mode, fnum, spp)
+        assert np.array_equal(u8.cpu().numpy(), ou8)
+    c.set_option("packet_samples_in_flight", 0)
+    # interior scene with absorbed nodes in its wide tree; an axis-aligned view through the middle pixel columns; ragged passes
+    pos, nrm, tex, tri = scenes.atrium(1, 0.05)
+    scene = mp.Scene(mp.TriangleBvh.build(pos, nrm, tex, tri, c))
+    orc = oracle.Bvh.build(pos, nrm, tex, tri)
+    for eye, at in (((-16.0, 4.2, 0.8), (12.0, 5.5, -0.5)), ((-15.0, 5.0, 0.0), (10.0, 5.0, 0.0))):
+        oc = oracle.Camera()
+        oracle.lib().mpo_camera_default(C.byref(oc))
+        oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(*eye), oracle.vec3(*at), oracle.vec3(0, 1, 0))
+        oc.f_number = 1e9  # pinhole: every ray of the centre column has an exactly zero direction component in the second view
+        cam = mp.Camera.default().look_at(eye, at, (0, 1, 0)).f_number(1e9)
+        spp = 96
+        of, _, _, _, _ = orc.render_image_mt(oracle.build_sampler(oc, *res), res[0], res[1], spp, 3, 32, 8)
+        fr = mp.FrameRenderer(scene, cam, mp.RenderSettings(32, spp, res, seed=3))
+        nxt = fr.render_pass(0, 70); fr.render_pass(nxt)
+        img, _ = fr.untile()
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(img.cpu().numpy()), bits(of)), (mode, eye)

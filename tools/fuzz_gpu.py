@@ -38,7 +38,7 @@ def run(cases, seed, ctx=None):
         scene, ob = scenes[name]
         w, h = int(rng.integers(17, 150)), int(rng.integers(9, 120))
         ts = int(rng.choice([8, 16, 24, 32, 64]))
-        spp = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 33, 70]))
+        spp = int(rng.choice([1, 2, 3, 5, 8, 16, 17, 33, 70, 64, 130]))   # >= 64: units of four and more passes (mask cache)
         seed = int(rng.integers(1 << 40))
         if rng.random() < 0.3:   # axis-aligned view: exact zero direction components at the image centre lines
             axis = int(rng.integers(3)); eye = np.zeros(3); eye[axis] = float(rng.choice([-6.0, 6.0])); at = np.zeros(3)
@@ -56,7 +56,8 @@ def run(cases, seed, ctx=None):
         s_opt = int(rng.choice([0, 0, 1, 4, 8, 16, 32, 64]))
         ctx.set_option("packet_samples_in_flight", s_opt)
         ctx.set_option("packet_stack_registers", int(rng.choice([64, 64, 3, 9])))
-        ctx.set_option("paths_pooled", int(rng.choice([0, 1, 2, 3, 3])))   # one pass per walk / pooled passes of the fused path kernel
+        ctx.set_option("paths_pooled", int(rng.choice([0, 1, 2, 3, 3])))
+        ctx.set_option("packet_mask_cache", int(rng.choice([0, 1, 2, 2])))   # the packet walk's per-unit child-rejection masks   # one pass per walk / pooled passes of the fused path kernel
         chunked = bool(rng.random() < 0.25)
         if chunked:
             spp = int(rng.choice([spp, 300, 513]))
@@ -121,6 +122,7 @@ def run(cases, seed, ctx=None):
     ctx.set_option("packet_samples_in_flight", 0)
     ctx.set_option("packet_stack_registers", 64)
     ctx.set_option("paths_pooled", 1)
+    ctx.set_option("packet_mask_cache", 1)
     return bad
 
 
