@@ -850,7 +850,8 @@ struct MaskCache {
     uint32_t* lds;  // this wave's header + entries, or nullptr: no packet-level rejection
 };
 // Wave-wide minima of six values and maxima of six values at once (every lane takes part; inactive rays hold the neutral element):
-// four DPP steps inside each row of 16, row_bcast15 / row_bcast31 across the rows, the totals end in lane 63.  The twelve
+// four DPP steps inside each row of 16, row_bcast15 / row_bcast31 across the rows, the totals end in LANE 63's registers (the
+// caller goes on in the vector domain and takes lane 63's verdict: twelve scalar registers would not fit beside the walk's).  The twelve
 // independent chains are interleaved step by step, so no instruction reads a register the previous two instructions wrote (the
 // DPP read-after-VALU-write hazard needs two wait states) and no s_nop is spent.
 #define MP_DPP_STEP12(CTRL)                                                                                             \
@@ -868,11 +869,6 @@ __device__ __forceinline__ void wave_min6_max6(float (&mn)[6], float (&mx)[6]) {
                  MP_DPP_STEP12("row_bcast:31 row_mask:0xc bank_mask:0xf")
                  : "+v"(mn[0]), "+v"(mn[1]), "+v"(mn[2]), "+v"(mn[3]), "+v"(mn[4]), "+v"(mn[5]), "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]),
                    "+v"(mx[3]), "+v"(mx[4]), "+v"(mx[5]));
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        mn[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mn[k]), 63));
-        mx[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mx[k]), 63));
-    }
 }
 // Called once per pass, before a sign-specialised walk with pattern `oct`: makes the cache's bounds B contain this pass's rays
 // (widening B and clearing the masks if they do not).  Returns false when the pass cannot use the cache (a non-finite component).
@@ -882,7 +878,7 @@ __device__ __forceinline__ bool mask_cache_begin_pass(const MaskCache& mc, const
                      fabsf(r.iy) < INFINITY && fabsf(r.iz) < INFINITY;
     if (__ballot(active && !fin) != 0) return false;
     const float val[6] = {r.ox, r.oy, r.oz, r.ix, r.iy, r.iz};
-    float pmin[6], pmax[6];  // wave-uniform after the reduction
+    float pmin[6], pmax[6];  // after the reduction: lane 63 holds the wave's bounds
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         pmin[k] = active ? val[k] : INFINITY;
@@ -891,22 +887,20 @@ __device__ __forceinline__ bool mask_cache_begin_pass(const MaskCache& mc, const
     wave_min6_max6(pmin, pmax);
     float* hdr = reinterpret_cast<float*>(mc.lds);  // omin[3], omax[3], imin[3], imax[3]
     const uint32_t state = __builtin_amdgcn_readfirstlane(mc.lds[12]);
-    bool inside = state == (oct | 0x100u);
-    if (inside) {  // P inside B ?
-        bool viol = false;
+    const bool same = state == (oct | 0x100u);
+    bool viol = !same;  // P inside B ?  (every lane compares its own values with the header; lane 63's are the wave's)
+    if (same) {
 #pragma unroll
         for (int k = 0; k < 3; k++)
             viol = viol || pmin[k] < hdr[k] || pmax[k] > hdr[3 + k] || pmin[3 + k] < hdr[6 + k] || pmax[3 + k] > hdr[9 + k];
-        inside = __ballot(viol) == 0;
     }
-    if (!inside) {
+    if ((__ballot(viol) >> 63) != 0) {
         // new bounds: this pass's, united with the old ones when they belong to the same sign pattern, widened by half the extent
         // (an inverse-direction bound never crosses zero: the sign pattern is part of the masks' meaning)
-        const bool keep = state == (oct | 0x100u);
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             float lo = pmin[k], hi = pmax[k];
-            if (keep) { lo = fminf(lo, hdr[k < 3 ? k : 3 + k]); hi = fmaxf(hi, hdr[k < 3 ? 3 + k : 6 + k]); }
+            if (same) { lo = fminf(lo, hdr[k < 3 ? k : 3 + k]); hi = fmaxf(hi, hdr[k < 3 ? 3 + k : 6 + k]); }
             const float pad = (hi - lo) * MP_MCACHE_PAD;
             float wlo = lo - pad, whi = hi + pad;
             if (k >= 3) {  // same sign as the pass's inverse directions (all of one sign, finite, non-zero)
@@ -918,13 +912,15 @@ __device__ __forceinline__ bool mask_cache_begin_pass(const MaskCache& mc, const
             pmin[k] = wlo; pmax[k] = whi;
         }
         wave_lds_sync();  // the reads above before the header is rewritten
-        if (lane == 0) {
+        if (lane == 63) {
 #pragma unroll
             for (int k = 0; k < 3; k++) { hdr[k] = pmin[k]; hdr[3 + k] = pmax[k]; hdr[6 + k] = pmin[3 + k]; hdr[9 + k] = pmax[3 + k]; }
             mc.lds[12] = oct | 0x100u;
         }
+        int l_ = lane;  // (re-derived here: the clear runs once per unit, its address is not worth a register across the walk)
+        asm volatile("" : "+v"(l_));
 #pragma unroll
-        for (int i = 0; i < kMaskCacheEntries / 64; i++) mc.lds[16 + i * 64 + lane] = 0xFFFFFFFFu;  // no node has this tag
+        for (int i = 0; i < kMaskCacheEntries / 64; i++) mc.lds[16 + i * 64 + l_] = 0xFFFFFFFFu;  // no node has this tag
         wave_lds_sync();
     }
     return true;
@@ -956,7 +952,8 @@ __device__ __forceinline__ bool bounds_may_hit(const float* b, const float bmn[3
 // +inf: a disabled ray is always "surely rejected") -- so every ballot below is already the masked result and "no ray left" is a
 // branch on VCC; det's magnitude guard is a v_cndmask, the three sign tests one minNum chain; loops are single-exit pair loops
 // with a scalar countdown; pushes are v_writelane; staleness is a low-water mark instead of a 64-bit mask.
-template <int MODE, int OCT, class Stack>
+// MC: the sign-specialised walk consults the per-unit mask cache `mcache` (never null then) instead of testing every child
+template <int MODE, int OCT, class Stack, bool MC = false>
 __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit,
                                                   uint32_t* mcache = nullptr) {
     constexpr bool PATCH_NAN = MODE == 2;
@@ -1032,7 +1029,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                     sp++;
                 }
             };
-            if (OCT >= 0 && mcache != nullptr) {
+            if (MC && OCT >= 0) {
                 // per-unit mask cache (see MaskCache): which children can ANY ray inside the unit's bounds pass?
                 const uint32_t cslot = 16u + (node & static_cast<uint32_t>(kMaskCacheEntries - 1));
                 const uint32_t e = __builtin_amdgcn_readfirstlane(mcache[cslot]);
@@ -1143,7 +1140,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
 }
 
 // OCTANTS: also instantiate the eight sign-specialised walks (the production kernels; the rest keep the generic slab).
-template <bool OCTANTS, class Stack>
+template <bool OCTANTS, class Stack, bool MC = false>
 __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit,
                                              const MaskCache& mc = MaskCache{nullptr}) {
     const bool slow = active && (fabsf(r.ix) == INFINITY || fabsf(r.iy) == INFINITY || fabsf(r.iz) == INFINITY);
@@ -1156,16 +1153,30 @@ __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, b
         const uint64_t nx = __ballot(active && r.ix < 0.0f), ny = __ballot(active && r.iy < 0.0f), nz = __ballot(active && r.iz < 0.0f);
         if ((nx == 0 || nx == am) && (ny == 0 || ny == am) && (nz == 0 || nz == am)) {
             const uint32_t oct = (nx ? 1u : 0u) | (ny ? 2u : 0u) | (nz ? 4u : 0u);
-            uint32_t* mcache = (mc.lds != nullptr && mask_cache_begin_pass(mc, r, active, oct)) ? mc.lds : nullptr;
-            switch (oct) {
-                case 0: trace_packet_impl<1, 0>(sc, r, active, st, hit, mcache); return;
-                case 1: trace_packet_impl<1, 1>(sc, r, active, st, hit, mcache); return;
-                case 2: trace_packet_impl<1, 2>(sc, r, active, st, hit, mcache); return;
-                case 3: trace_packet_impl<1, 3>(sc, r, active, st, hit, mcache); return;
-                case 4: trace_packet_impl<1, 4>(sc, r, active, st, hit, mcache); return;
-                case 5: trace_packet_impl<1, 5>(sc, r, active, st, hit, mcache); return;
-                case 6: trace_packet_impl<1, 6>(sc, r, active, st, hit, mcache); return;
-                default: trace_packet_impl<1, 7>(sc, r, active, st, hit, mcache); return;
+            if (MC) {  // kernels with a mask cache: the sign-specialised walks use it; a pass with a non-finite component takes the generic walk
+                if (mask_cache_begin_pass(mc, r, active, oct)) {
+                    switch (oct) {
+                        case 0: trace_packet_impl<1, 0, Stack, true>(sc, r, active, st, hit, mc.lds); return;
+                        case 1: trace_packet_impl<1, 1, Stack, true>(sc, r, active, st, hit, mc.lds); return;
+                        case 2: trace_packet_impl<1, 2, Stack, true>(sc, r, active, st, hit, mc.lds); return;
+                        case 3: trace_packet_impl<1, 3, Stack, true>(sc, r, active, st, hit, mc.lds); return;
+                        case 4: trace_packet_impl<1, 4, Stack, true>(sc, r, active, st, hit, mc.lds); return;
+                        case 5: trace_packet_impl<1, 5, Stack, true>(sc, r, active, st, hit, mc.lds); return;
+                        case 6: trace_packet_impl<1, 6, Stack, true>(sc, r, active, st, hit, mc.lds); return;
+                        default: trace_packet_impl<1, 7, Stack, true>(sc, r, active, st, hit, mc.lds); return;
+                    }
+                }
+            } else {
+                switch (oct) {
+                    case 0: trace_packet_impl<1, 0>(sc, r, active, st, hit); return;
+                    case 1: trace_packet_impl<1, 1>(sc, r, active, st, hit); return;
+                    case 2: trace_packet_impl<1, 2>(sc, r, active, st, hit); return;
+                    case 3: trace_packet_impl<1, 3>(sc, r, active, st, hit); return;
+                    case 4: trace_packet_impl<1, 4>(sc, r, active, st, hit); return;
+                    case 5: trace_packet_impl<1, 5>(sc, r, active, st, hit); return;
+                    case 6: trace_packet_impl<1, 6>(sc, r, active, st, hit); return;
+                    default: trace_packet_impl<1, 7>(sc, r, active, st, hit); return;
+                }
             }
         }
     }
@@ -1434,7 +1445,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     constexpr int BH = 64 / S / BW;
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const int pix = lane / S, sub = lane % S;
-    const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1));
     uint32_t qstate = blockIdx.x % kWorkQueues;
     // per-unit mask cache of the packet-level child rejection (MaskCache): this wave's header + entries in LDS
     MaskCache mc{nullptr};
@@ -1493,7 +1503,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                             trace_packet<false>(W.scene, r, go, st, h);
                         } else {
                             RegStack st(lds, lane);
-                            trace_packet<(S >= 8 && S <= 32)>(W.scene, r, go, st, h, mc);
+                            trace_packet<(S >= 8 && S <= 32), RegStack, MCACHE>(W.scene, r, go, st, h, mc);
                         }
                     }
                 }
@@ -1512,7 +1522,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                 if (hit) c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);
             }
             // alpha sums 1.0 per hit: an exact integer in f32, so the order is irrelevant
-            cnt += static_cast<float>(__popcll(__ballot(hit) & pixel_lanes));
+            {   // (the mask of this pixel's lanes is rebuilt from the lane id here: two registers less across the walk)
+                int l_ = lane;
+                asm volatile("" : "+v"(l_));
+                const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (l_ & ~(S - 1));
+                cnt += static_cast<float>(__popcll(__ballot(hit) & pixel_lanes));
+            }
             add_samples_in_order<S>(acc, c, lane);  // misses add +0.0 (exact)
             if (H.chunked && ((s0 + S) & (kSumChunk - 1u)) == 0u && s0 + S <= s_end) chunk_flush(H, off, inpix && sub == 0, acc);
         }
