@@ -376,6 +376,13 @@ int upload_scene(mp_scene* s) {
     for (size_t p = 0; p < np; p++)
         for (int i = 0; i < 8; i++)
             for (int k = 0; k < 9; k++) tris_aos[(p * 8 + i) * kTriDwords + k] = tris[p * kPacketDwords + k * 8 + i];
+    // magnitude bound behind the packet walk's triangle masks (kernels.hip, tri_may_hit): no overflow in the interval evaluation
+    s->dev.tris_bounded = 1u;
+    for (size_t i = 0; i < np * 8 && s->dev.tris_bounded; i++)
+        for (int k = 0; k < 9; k++) {
+            const float v = tris_aos[i * kTriDwords + k];
+            if (!(std::fabs(v) <= (k < 3 ? 1073741824.0f : 2147483648.0f))) { s->dev.tris_bounded = 0u; break; }
+        }
     auto up = [&](void** dst, const void* src, size_t bytes) -> int {
         bytes = std::max<size_t>(bytes, 16);
         MP_HIP(hipMalloc(dst, bytes));

@@ -845,82 +845,103 @@ __device__ __forceinline__ uint32_t uniform_u(float f) { return __builtin_amdgcn
 #define MP_MCACHE_PAD 0.5f  // widening of the unit's bounds on either side, in extents of the pass that sets them (A/B: profiles/r03_notes.md)
 #endif
 constexpr int kMaskCacheEntries = 512;                      // direct-mapped: node index & 511 ; entry = node << 8 | mask
-constexpr int kMaskCacheDwords = 16 + kMaskCacheEntries;    // header: B (12 floats), [12] = sign pattern | 0x100 when valid (0xFFFFFFFF: none)
+constexpr int kMaskCacheHeader = 32;                        // B: [0..11] origin / inverse-direction bounds, [12] = sign pattern | 0x100 when valid (0xFFFFFFFF: none), [16..21] direction bounds
+constexpr int kLeafCacheEntries = 128;                      // direct-mapped: first packet of the leaf & 127 ; tag = first packet, mask = 64 bits (triangle i of the leaf)
+constexpr int kLeafTagBase = kMaskCacheHeader + kMaskCacheEntries;
+constexpr int kLeafMaskBase = kLeafTagBase + kLeafCacheEntries;   // uint2 per entry (8-byte aligned)
+constexpr int kMaskCacheDwords = kLeafMaskBase + 2 * kLeafCacheEntries;
+static_assert((kLeafMaskBase % 2) == 0 && (kMaskCacheDwords % 4) == 0, "LDS alignment of the leaf masks / of the next wave's header");
+constexpr float kCoordCap = 1073741824.0f;                  // 2^30: magnitude bound of ray origins and triangle vertices for the triangle masks (see tri_may_hit)
 struct MaskCache {
     uint32_t* lds;  // this wave's header + entries, or nullptr: no packet-level rejection
 };
-// Wave-wide minima of six values and maxima of six values at once (every lane takes part; inactive rays hold the neutral element):
+// Wave-wide minima of N values and maxima of N values at once (every lane takes part; inactive rays hold the neutral element):
 // four DPP steps inside each row of 16, row_bcast15 / row_bcast31 across the rows, the totals end in LANE 63's registers (the
-// caller goes on in the vector domain and takes lane 63's verdict: twelve scalar registers would not fit beside the walk's).  The twelve
+// caller goes on in the vector domain and takes lane 63's verdict: the scalar registers would not fit beside the walk's).  The
 // independent chains are interleaved step by step, so no instruction reads a register the previous two instructions wrote (the
 // DPP read-after-VALU-write hazard needs two wait states) and no s_nop is spent.
-#define MP_DPP_STEP12(CTRL)                                                                                             \
+#define MP_DPP_STEP6(CTRL)                                                                                              \
     "v_min_f32_dpp %0, %0, %0 " CTRL "\n\tv_min_f32_dpp %1, %1, %1 " CTRL "\n\tv_min_f32_dpp %2, %2, %2 " CTRL "\n\t"         \
-    "v_min_f32_dpp %3, %3, %3 " CTRL "\n\tv_min_f32_dpp %4, %4, %4 " CTRL "\n\tv_min_f32_dpp %5, %5, %5 " CTRL "\n\t"         \
-    "v_max_f32_dpp %6, %6, %6 " CTRL "\n\tv_max_f32_dpp %7, %7, %7 " CTRL "\n\tv_max_f32_dpp %8, %8, %8 " CTRL "\n\t"         \
-    "v_max_f32_dpp %9, %9, %9 " CTRL "\n\tv_max_f32_dpp %10, %10, %10 " CTRL "\n\tv_max_f32_dpp %11, %11, %11 " CTRL "\n\t"
-__device__ __forceinline__ void wave_min6_max6(float (&mn)[6], float (&mx)[6]) {
+    "v_max_f32_dpp %3, %3, %3 " CTRL "\n\tv_max_f32_dpp %4, %4, %4 " CTRL "\n\tv_max_f32_dpp %5, %5, %5 " CTRL "\n\t"
+__device__ __forceinline__ void wave_min3_max3(float (&mn)[3], float (&mx)[3]) {
     asm volatile("s_nop 1\n\t"  // the operands may come straight out of VALU instructions
-                 MP_DPP_STEP12("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 MP_DPP_STEP12("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 MP_DPP_STEP12("row_half_mirror row_mask:0xf bank_mask:0xf")
-                 MP_DPP_STEP12("row_mirror row_mask:0xf bank_mask:0xf")
-                 MP_DPP_STEP12("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 MP_DPP_STEP12("row_bcast:31 row_mask:0xc bank_mask:0xf")
-                 : "+v"(mn[0]), "+v"(mn[1]), "+v"(mn[2]), "+v"(mn[3]), "+v"(mn[4]), "+v"(mn[5]), "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]),
-                   "+v"(mx[3]), "+v"(mx[4]), "+v"(mx[5]));
+                 MP_DPP_STEP6("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 MP_DPP_STEP6("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 MP_DPP_STEP6("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 MP_DPP_STEP6("row_mirror row_mask:0xf bank_mask:0xf")
+                 MP_DPP_STEP6("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 MP_DPP_STEP6("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 : "+v"(mn[0]), "+v"(mn[1]), "+v"(mn[2]), "+v"(mx[0]), "+v"(mx[1]), "+v"(mx[2]));
 }
 // Called once per pass, before a sign-specialised walk with pattern `oct`: makes the cache's bounds B contain this pass's rays
-// (widening B and clearing the masks if they do not).  Returns false when the pass cannot use the cache (a non-finite component).
+// (widening B and clearing the masks if they do not).  Returns false when the pass cannot use the cache: a non-finite inverse
+// direction, an origin beyond 2^30 or a direction component beyond 2 in magnitude (tri_may_hit's no-overflow argument).
+// B = origin, inverse-direction and direction bounds; three groups of (3 minima, 3 maxima), header slots g*6 .. g*6+5 for the first
+// two and 16..21 for the directions.
 __device__ __forceinline__ bool mask_cache_begin_pass(const MaskCache& mc, const Ray& r, bool active, uint32_t oct) {
     const int lane = static_cast<int>(threadIdx.x) & 63;
-    const bool fin = fabsf(r.ox) < INFINITY && fabsf(r.oy) < INFINITY && fabsf(r.oz) < INFINITY && fabsf(r.ix) < INFINITY &&
-                     fabsf(r.iy) < INFINITY && fabsf(r.iz) < INFINITY;
+    const bool fin = fabsf(r.ox) <= kCoordCap && fabsf(r.oy) <= kCoordCap && fabsf(r.oz) <= kCoordCap && fabsf(r.ix) < INFINITY &&
+                     fabsf(r.iy) < INFINITY && fabsf(r.iz) < INFINITY && fabsf(r.dx) <= 2.0f && fabsf(r.dy) <= 2.0f && fabsf(r.dz) <= 2.0f;
     if (__ballot(active && !fin) != 0) return false;
-    const float val[6] = {r.ox, r.oy, r.oz, r.ix, r.iy, r.iz};
-    float pmin[6], pmax[6];  // after the reduction: lane 63 holds the wave's bounds
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        pmin[k] = active ? val[k] : INFINITY;
-        pmax[k] = active ? val[k] : -INFINITY;
-    }
-    wave_min6_max6(pmin, pmax);
-    float* hdr = reinterpret_cast<float*>(mc.lds);  // omin[3], omax[3], imin[3], imax[3]
+    float* hdr = reinterpret_cast<float*>(mc.lds);
     const uint32_t state = __builtin_amdgcn_readfirstlane(mc.lds[12]);
     const bool same = state == (oct | 0x100u);
-    bool viol = !same;  // P inside B ?  (every lane compares its own values with the header; lane 63's are the wave's)
-    if (same) {
+    const float val[3][3] = {{r.ox, r.oy, r.oz}, {r.ix, r.iy, r.iz}, {r.dx, r.dy, r.dz}};
+    float pmin[3][3], pmax[3][3];  // after the reductions: lane 63 holds the wave's bounds
+    bool viol = !same;             // P inside B ?  (every lane compares its own values with the header; lane 63's are the wave's)
 #pragma unroll
-        for (int k = 0; k < 3; k++)
-            viol = viol || pmin[k] < hdr[k] || pmax[k] > hdr[3 + k] || pmin[3 + k] < hdr[6 + k] || pmax[3 + k] > hdr[9 + k];
+    for (int g = 0; g < 3; g++) {
+        const int base = g == 2 ? 16 : g * 6;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            pmin[g][k] = active ? val[g][k] : INFINITY;
+            pmax[g][k] = active ? val[g][k] : -INFINITY;
+        }
+        wave_min3_max3(pmin[g], pmax[g]);
+        if (same) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) viol = viol || pmin[g][k] < hdr[base + k] || pmax[g][k] > hdr[base + 3 + k];
+        }
     }
     if ((__ballot(viol) >> 63) != 0) {
         // new bounds: this pass's, united with the old ones when they belong to the same sign pattern, widened by half the extent
-        // (an inverse-direction bound never crosses zero: the sign pattern is part of the masks' meaning)
+        // (an inverse-direction bound never crosses zero: the sign pattern is part of the node masks' meaning; origin bounds stay
+        // within 2^31 and direction bounds within 2: every pass that gets here lies well inside)
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
-            float lo = pmin[k], hi = pmax[k];
-            if (same) { lo = fminf(lo, hdr[k < 3 ? k : 3 + k]); hi = fmaxf(hi, hdr[k < 3 ? 3 + k : 6 + k]); }
-            const float pad = (hi - lo) * MP_MCACHE_PAD;
-            float wlo = lo - pad, whi = hi + pad;
-            if (k >= 3) {  // same sign as the pass's inverse directions (all of one sign, finite, non-zero)
-                if ((wlo < 0.0f) != (lo < 0.0f) || wlo == 0.0f) wlo = lo;
-                if ((whi < 0.0f) != (hi < 0.0f) || whi == 0.0f) whi = hi;
+        for (int g = 0; g < 3; g++) {
+            const int base = g == 2 ? 16 : g * 6;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                float lo = pmin[g][k], hi = pmax[g][k];
+                if (same) { lo = fminf(lo, hdr[base + k]); hi = fmaxf(hi, hdr[base + 3 + k]); }
+                const float pad = (hi - lo) * MP_MCACHE_PAD;
+                float wlo = lo - pad, whi = hi + pad;
+                if (g == 1) {  // same sign as the pass's inverse directions (all of one sign, finite, non-zero)
+                    if ((wlo < 0.0f) != (lo < 0.0f) || wlo == 0.0f) wlo = lo;
+                    if ((whi < 0.0f) != (hi < 0.0f) || whi == 0.0f) whi = hi;
+                    if (!(fabsf(wlo) < INFINITY)) wlo = lo;
+                    if (!(fabsf(whi) < INFINITY)) whi = hi;
+                } else {
+                    const float cap = g == 0 ? 2.0f * kCoordCap : 2.0f;
+                    wlo = fmaxf(wlo, -cap); whi = fminf(whi, cap);
+                }
+                pmin[g][k] = wlo; pmax[g][k] = whi;
             }
-            if (!(fabsf(wlo) < INFINITY)) wlo = lo;
-            if (!(fabsf(whi) < INFINITY)) whi = hi;
-            pmin[k] = wlo; pmax[k] = whi;
         }
         wave_lds_sync();  // the reads above before the header is rewritten
         if (lane == 63) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) { hdr[k] = pmin[k]; hdr[3 + k] = pmax[k]; hdr[6 + k] = pmin[3 + k]; hdr[9 + k] = pmax[3 + k]; }
+            for (int g = 0; g < 3; g++) {
+                const int base = g == 2 ? 16 : g * 6;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { hdr[base + k] = pmin[g][k]; hdr[base + 3 + k] = pmax[g][k]; }
+            }
             mc.lds[12] = oct | 0x100u;
         }
         int l_ = lane;  // (re-derived here: the clear runs once per unit, its address is not worth a register across the walk)
         asm volatile("" : "+v"(l_));
 #pragma unroll
-        for (int i = 0; i < kMaskCacheEntries / 64; i++) mc.lds[16 + i * 64 + l_] = 0xFFFFFFFFu;  // no node has this tag
+        for (int i = 0; i < (kMaskCacheEntries + kLeafCacheEntries) / 64; i++) mc.lds[kMaskCacheHeader + i * 64 + l_] = 0xFFFFFFFFu;  // no node / leaf has this tag
         wave_lds_sync();
     }
     return true;
@@ -939,6 +960,60 @@ __device__ __forceinline__ bool bounds_may_hit(const float* b, const float bmn[3
     }
     const float t1 = fmaxf(fmaxf(L[0], 0.0f), fmaxf(L[1], L[2])), t2 = fminf(U[0], fminf(U[1], U[2]));
     return !(t1 > t2);
+}
+
+// ---- ... and packet-level TRIANGLE rejection with the same bounds --------------------------------------------------------------------
+// Counted on the metric's frame (tools/sim_tri_reject.py): a pass of 64 rays through two pixels tests 53 triangles and 3.8 of them are
+// hit by some ray; with the unit's bounds B (origins, directions) 41 of the 53 can be PROVEN missed by every ray inside B, once per
+// work unit and leaf: the leaf's 64-bit mask "triangle i may be hit" is cached next to the node masks and a pass tests the survivors.
+// The proof is the Moeller-Trumbore expression sequence of triangle.rs:183-217 itself, evaluated on intervals: every operation of
+// it (fl(a*b), fl(a*b+c), fl(a-b), fl(1/x) on an interval without zero) is monotone in each operand while the others are fixed, so
+// the same f32 operation evaluated at the corners of the operand intervals bounds the operation's result for every ray inside B --
+// no error analysis, the bounds contain the very f32 values the per-ray test computes.  A triangle is skipped when the bounds show
+// u < 0, v < 0, u + v > 1 or t < 0 for all of them (:125 then accepts for no ray).  No NaN can arise on the way: every origin bound
+// is within 2^31, every direction bound within 2, every vertex within 2^30 and every edge within 2^31 (DevScene::tris_bounded,
+// mask_cache_begin_pass), which keeps all intermediate bounds finite up to the reciprocal (|t numerator| < 2^98); a determinant
+// interval that touches zero or has an infinite reciprocal keeps the triangle; after that every value is one product of finite
+// numbers (never NaN), and the only sum (u + v) can at worst be inf - inf = NaN, which compares false and keeps the triangle.
+struct Iv {
+    float lo, hi;
+};
+__device__ __forceinline__ Iv iv_neg(const Iv a) { return Iv{-a.hi, -a.lo}; }
+__device__ __forceinline__ Iv iv_mul_c(const Iv a, const float c) {  // fl(a * c)
+    const float p = a.lo * c, q = a.hi * c;
+    return Iv{fminf(p, q), fmaxf(p, q)};
+}
+__device__ __forceinline__ Iv iv_mul(const Iv a, const Iv b) {  // fl(a * b)
+    const float p1 = a.lo * b.lo, p2 = a.lo * b.hi, p3 = a.hi * b.lo, p4 = a.hi * b.hi;
+    return Iv{fminf(fminf(p1, p2), fminf(p3, p4)), fmaxf(fmaxf(p1, p2), fmaxf(p3, p4))};
+}
+__device__ __forceinline__ Iv iv_fma_c(const Iv a, const float c, const Iv z) {  // fl(a * c + z)
+    return Iv{fminf(__builtin_fmaf(a.lo, c, z.lo), __builtin_fmaf(a.hi, c, z.lo)), fmaxf(__builtin_fmaf(a.lo, c, z.hi), __builtin_fmaf(a.hi, c, z.hi))};
+}
+__device__ __forceinline__ Iv iv_fma(const Iv a, const Iv b, const Iv z) {  // fl(a * b + z)
+    const float l1 = __builtin_fmaf(a.lo, b.lo, z.lo), l2 = __builtin_fmaf(a.lo, b.hi, z.lo), l3 = __builtin_fmaf(a.hi, b.lo, z.lo), l4 = __builtin_fmaf(a.hi, b.hi, z.lo);
+    const float h1 = __builtin_fmaf(a.lo, b.lo, z.hi), h2 = __builtin_fmaf(a.lo, b.hi, z.hi), h3 = __builtin_fmaf(a.hi, b.lo, z.hi), h4 = __builtin_fmaf(a.hi, b.hi, z.hi);
+    return Iv{fminf(fminf(l1, l2), fminf(l3, l4)), fmaxf(fmaxf(h1, h2), fmaxf(h3, h4))};
+}
+// can any ray with origin / direction inside the bounds `b` (mask-cache header) hit the triangle {v0, e1, e2}?
+__device__ __forceinline__ bool tri_may_hit(const float* b, const float (&v0)[3], const float (&e1)[3], const float (&e2)[3]) {
+    const Iv d[3] = {Iv{b[16], b[19]}, Iv{b[17], b[20]}, Iv{b[18], b[21]}};
+    // h = (fms(dy, e2z, dz * e2y), fms(dz, e2x, dx * e2z), fms(dx, e2y, dy * e2x)) ; fms(a, b, c) = fma(a, b, -c)
+    const Iv h[3] = {iv_fma_c(d[1], e2[2], iv_neg(iv_mul_c(d[2], e2[1]))), iv_fma_c(d[2], e2[0], iv_neg(iv_mul_c(d[0], e2[2]))),
+                     iv_fma_c(d[0], e2[1], iv_neg(iv_mul_c(d[1], e2[0])))};
+    // fma_dot(a, b) = fma(az, bz, fma(ay, by, ax * bx))
+    const Iv det = iv_fma_c(h[2], e1[2], iv_fma_c(h[1], e1[1], iv_mul_c(h[0], e1[0])));
+    if (!(det.lo > 0.0f || det.hi < 0.0f)) return true;
+    const Iv inv = Iv{1.0f / det.hi, 1.0f / det.lo};
+    if (!(fabsf(inv.lo) < INFINITY && fabsf(inv.hi) < INFINITY)) return true;
+    const Iv s[3] = {Iv{b[0] - v0[0], b[3] - v0[0]}, Iv{b[1] - v0[1], b[4] - v0[1]}, Iv{b[2] - v0[2], b[5] - v0[2]}};
+    const Iv u = iv_mul(inv, iv_fma(s[2], h[2], iv_fma(s[1], h[1], iv_mul(s[0], h[0]))));
+    const Iv q[3] = {iv_fma_c(s[1], e1[2], iv_neg(iv_mul_c(s[2], e1[1]))), iv_fma_c(s[2], e1[0], iv_neg(iv_mul_c(s[0], e1[2]))),
+                     iv_fma_c(s[0], e1[1], iv_neg(iv_mul_c(s[1], e1[0])))};
+    const Iv v = iv_mul(inv, iv_fma(d[2], q[2], iv_fma(d[1], q[1], iv_mul(d[0], q[0]))));
+    const Iv t = iv_mul(inv, iv_fma_c(q[2], e2[2], iv_fma_c(q[1], e2[1], iv_mul_c(q[0], e2[0]))));
+    const bool miss = u.hi < 0.0f || v.hi < 0.0f || (u.lo + v.lo) > 1.0f || t.hi < 0.0f;
+    return !miss;
 }
 
 // MODE 1: every active ray has finite inverse directions (no 0*inf, so the NaN patches of aabb.rs:262-267 are dead code).
@@ -1031,7 +1106,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
             };
             if (MC && OCT >= 0) {
                 // per-unit mask cache (see MaskCache): which children can ANY ray inside the unit's bounds pass?
-                const uint32_t cslot = 16u + (node & static_cast<uint32_t>(kMaskCacheEntries - 1));
+                const uint32_t cslot = static_cast<uint32_t>(kMaskCacheHeader) + (node & static_cast<uint32_t>(kMaskCacheEntries - 1));
                 const uint32_t e = __builtin_amdgcn_readfirstlane(mcache[cslot]);
                 uint32_t todo;
                 if ((e >> 8) == node) {
@@ -1121,6 +1196,53 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 bprim = acc ? tri : bprim;
                 changed |= __ballot(acc);
             };
+            if (MC && OCT >= 0) {
+                // per-unit triangle masks (see tri_may_hit): which triangles of this leaf can ANY ray inside the unit's bounds hit?
+                const uint32_t ls = first & static_cast<uint32_t>(kLeafCacheEntries - 1);
+                const uint32_t tag = mcache[kLeafTagBase + ls];
+                const uint2 tm = reinterpret_cast<const uint2*>(mcache + kLeafMaskBase)[ls];
+                uint64_t todo;
+                if (__builtin_amdgcn_readfirstlane(tag) == first) {
+                    todo = __builtin_amdgcn_readfirstlane(tm.x) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(tm.y)) << 32);
+                } else {  // first visit of this leaf under the current bounds: lane j = triangle j, one coalesced read of the leaf's records
+                    const uint32_t j = threadIdx.x & 63u;
+                    bool keep = false;
+                    if (j < n_real) {
+                        const float* tv = sc.tris_aos + (static_cast<size_t>(first) * 8 + j) * kTriDwords;
+                        const float v0[3] = {tv[0], tv[1], tv[2]}, e1[3] = {tv[3], tv[4], tv[5]}, e2[3] = {tv[6], tv[7], tv[8]};
+                        keep = tri_may_hit(reinterpret_cast<const float*>(mcache), v0, e1, e2);
+                    }
+                    todo = __ballot(keep);
+                    if (j == 0u) {
+                        mcache[kLeafTagBase + ls] = first;
+                        reinterpret_cast<uint2*>(mcache + kLeafMaskBase)[ls] = make_uint2(static_cast<uint32_t>(todo), static_cast<uint32_t>(todo >> 32));
+                    }
+                }
+                // the surviving triangles, ascending = (packet, lane) order; two register sets alternate: the next survivor's record
+                // is fetched while this one is tested
+                if (todo != 0) {
+                    uint32_t ca = static_cast<uint32_t>(__builtin_ctzll(todo));
+                    todo &= todo - 1;
+                    kfp ta = tp + ca * kTriDwords;
+                    float a0 = ta[0], a1 = ta[1], a2 = ta[2], a3 = ta[3], a4 = ta[4], a5 = ta[5], a6 = ta[6], a7 = ta[7], a8 = ta[8];
+                    for (;;) {
+                        if (todo == 0) { test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + ca); break; }
+                        const uint32_t cb = static_cast<uint32_t>(__builtin_ctzll(todo));
+                        todo &= todo - 1;
+                        kfp tb = tp + cb * kTriDwords;
+                        const float b0 = tb[0], b1 = tb[1], b2 = tb[2], b3 = tb[3], b4 = tb[4], b5 = tb[5], b6 = tb[6], b7 = tb[7], b8 = tb[8];
+                        test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + ca);
+                        if (todo == 0) { test(b0, b1, b2, b3, b4, b5, b6, b7, b8, first * 8u + cb); break; }
+                        ca = static_cast<uint32_t>(__builtin_ctzll(todo));
+                        todo &= todo - 1;
+                        ta = tp + ca * kTriDwords;
+                        a0 = ta[0]; a1 = ta[1]; a2 = ta[2]; a3 = ta[3]; a4 = ta[4]; a5 = ta[5]; a6 = ta[6]; a7 = ta[7]; a8 = ta[8];
+                        test(b0, b1, b2, b3, b4, b5, b6, b7, b8, first * 8u + cb);
+                    }
+                }
+                if (changed != 0) stale_top = sp;
+                continue;
+            }
             // two register sets (A, B) alternate: B is fetched while A is tested and vice versa (the array has tail padding)
             float a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3], a4 = tp[4], a5 = tp[5], a6 = tp[6], a7 = tp[7], a8 = tp[8];
             uint32_t tri = first * 8u;
@@ -2607,12 +2729,12 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
         else hipLaunchKernelGGL((render_tiles_packet_kernel<SV, false, W>), dim3(grid), dim3(256), 0, st, P);           \
     } while (0)
     // per-unit mask cache of the packet-level child rejection: units of at least four passes, stack in registers, node indices
-    // that fit the cache tag; 2 112 bytes of LDS per wave
+    // that fit the cache tag, triangle coordinates within the bound of the triangle masks; 3 712 bytes of LDS per wave
 #ifndef MP_MCACHE_WPE
 #define MP_MCACHE_WPE 8
 #endif
     // (big scenes only: a teapot packet visits 2.5 nodes per pass, fewer than the per-pass bounds cost -- 12.3 against 11.8 ms)
-    const bool mcache = (L.mask_cache == 2u || (L.mask_cache == 1u && big)) && !lds_stack && !obj && (S == 16 || S == 32) && nspp >= 4u * static_cast<uint32_t>(S) && L.scene.inner_count < (1u << 24);
+    const bool mcache = (L.mask_cache == 2u || (L.mask_cache == 1u && big)) && !lds_stack && !obj && (S == 16 || S == 32) && nspp >= 4u * static_cast<uint32_t>(S) && L.scene.inner_count < (1u << 24) && L.scene.tris_bounded != 0u;
     if (mcache) {
         const uint32_t clds = 4u * kMaskCacheDwords * 4u;
         if (S == 32) hipLaunchKernelGGL((render_tiles_packet_kernel<32, false, MP_MCACHE_WPE, false, true>), dim3(grid), dim3(256), clds, st, P);

@@ -134,6 +134,7 @@ struct DevScene {
     uint32_t stack_cap = 1;          // exact traversal-stack bound (upload_scene)
     uint32_t packet_stack_regs = 64; // entries of the packet walk's stack held in registers (test knob, <= 64)
     uint32_t boxes_ordered = 0;      // every real child box has min <= max on all axes (sign-specialised slab test allowed)
+    uint32_t tris_bounded = 0;       // every triangle record is finite with |v0| <= 2^30, |e1|, |e2| <= 2^31 (packet-level triangle masks allowed: tri_may_hit)
     // union of the root inner node's (non-null) decompressed child boxes: exact conservative ray pre-test
     uint32_t has_pre = 0;
     float pre_min[3] = {0, 0, 0}, pre_max[3] = {0, 0, 0};
