@@ -204,8 +204,9 @@ int mp_ctx_device(const mp_ctx *ctx, int *device_id, int *cu_count);
  * a wavefront traces per pass (64 / value pixels side by side); sets the size of a work unit.  "packet_rays_per_lane" (1 default,
  * or 2): 2 = 128-ray walks, two rays per lane (measured slower on MI355X; kept as the measured alternative).  "blocks_per_cu"
  * (0 = as many as fit, or 1..8): resident workgroups per CU, a diagnostic knob for occupancy studies.  "packet_mask_cache" (1
- * default): the packet walk's per-work-unit cache of "children no ray of the unit can hit" masks (exact: interval arithmetic on
- * bounds of the unit's rays): 0 = off, 2 = always, 1 = for scenes whose traversal arrays exceed 1 MB.  "paths_pooled" (MP_FLAG_PATHS
+ * default): the packet walk's per-work-unit cache of "children / triangles no ray of the unit can hit" masks (exact: interval
+ * evaluation of the reference's own tests on bounds of the unit's rays): 0 = off, 1 or 2 = on wherever a work unit has at least
+ * four passes (2 is kept for callers of earlier builds, where 1 meant big scenes only).  "paths_pooled" (MP_FLAG_PATHS
  * without MP_FLAG_WAVEFRONT; 1 default): 0 = one pass of 8 samples per walk of the bounce rays, 2 / 3 = two / up to four passes share
  * one walk over a per-wave ray queue in global memory (fewer idle lane groups at the end of every walk), 1 = the latter for scenes
  * whose traversal arrays exceed 1 MB.  Results never depend on any of them (tests sweep them). */

@@ -582,7 +582,7 @@ int mp_ctx_set_option(mp_ctx* ctx, const char* key, int value) {
         return MP_OK;
     }
     if (std::strcmp(key, "packet_mask_cache") == 0) {
-        if (value < 0 || value > 2) return fail(MP_ERR_INVALID, "packet_mask_cache must be 0 (off), 1 (scenes whose traversal arrays exceed 1 MB) or 2 (always)");
+        if (value < 0 || value > 2) return fail(MP_ERR_INVALID, "packet_mask_cache must be 0 (off), 1 or 2 (on)");
         ctx->mask_cache.store(static_cast<uint32_t>(value));
         return MP_OK;
     }

@@ -842,7 +842,7 @@ __device__ __forceinline__ uint32_t uniform_u(float f) { return __builtin_amdgcn
 // inverse direction lie in B: the reference pushes the child for none of them (ray_bvh_intersection.rs:158).  No NaN can arise: all
 // inputs are finite, inv is never 0, and B's inverse bounds keep the sign of the pattern.
 #ifndef MP_MCACHE_PAD
-#define MP_MCACHE_PAD 0.5f  // widening of the unit's bounds on either side, in extents of the pass that sets them (A/B: profiles/r03_notes.md)
+#define MP_MCACHE_PAD 0.25f  // widening of the unit's bounds on either side, in extents of the pass that sets them (A/B: 0.0625 .. 1, profiles/r03_notes.md)
 #endif
 constexpr int kMaskCacheEntries = 512;                      // direct-mapped: node index & 511 ; entry = node << 8 | mask
 constexpr int kMaskCacheHeader = 32;                        // B: [0..11] origin / inverse-direction bounds, [12] = sign pattern | 0x100 when valid (0xFFFFFFFF: none), [16..21] direction bounds
@@ -1016,6 +1016,26 @@ __device__ __forceinline__ bool tri_may_hit(const float* b, const float (&v0)[3]
     return !miss;
 }
 
+// The triangle masks of one leaf (first packet `first`, n_real triangles), computed and stored in the unit's cache: lane j = triangle
+// j, one coalesced read of the leaf's records.  A real call: its registers are needed once per unit and leaf, and inlined they
+// would push the walk's per-ray state out of the 64 registers an 8-wave kernel has.
+__device__ __noinline__ uint64_t leaf_mask_slow(const float* __restrict__ tris_aos, uint32_t* mcache, uint32_t first, uint32_t n_real) {
+    const uint32_t j = threadIdx.x & 63u;
+    bool keep = false;
+    if (j < n_real) {
+        const float* tv = tris_aos + (static_cast<size_t>(first) * 8 + j) * kTriDwords;
+        const float v0[3] = {tv[0], tv[1], tv[2]}, e1[3] = {tv[3], tv[4], tv[5]}, e2[3] = {tv[6], tv[7], tv[8]};
+        keep = tri_may_hit(reinterpret_cast<const float*>(mcache), v0, e1, e2);
+    }
+    const uint64_t todo = __ballot(keep);
+    if (j == 0u) {
+        const uint32_t ls = first & static_cast<uint32_t>(kLeafCacheEntries - 1);
+        mcache[kLeafTagBase + ls] = first;
+        reinterpret_cast<uint2*>(mcache + kLeafMaskBase)[ls] = make_uint2(static_cast<uint32_t>(todo), static_cast<uint32_t>(todo >> 32));
+    }
+    return todo;
+}
+
 // MODE 1: every active ray has finite inverse directions (no 0*inf, so the NaN patches of aabb.rs:262-267 are dead code).
 // MODE 2: literal aabb.rs:254-284.
 //
@@ -1109,7 +1129,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 const uint32_t cslot = static_cast<uint32_t>(kMaskCacheHeader) + (node & static_cast<uint32_t>(kMaskCacheEntries - 1));
                 const uint32_t e = __builtin_amdgcn_readfirstlane(mcache[cslot]);
                 uint32_t todo;
-                if ((e >> 8) == node) {
+                if (__builtin_expect((e >> 8) == node, 1)) {
                     todo = e & 0xFFu;
                 } else {  // first visit of this node under the current bounds: lane j = child j, records through one vector load pair
                     const int cj = static_cast<int>(threadIdx.x) & 7;
@@ -1124,6 +1144,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                     if ((threadIdx.x & 63u) == 0u) mcache[cslot] = (node << 8) | todo;
                 }
                 // the surviving children, ascending, through the scalar unit: the next survivor's record is fetched while this one is tested
+                // (one register set rotated through moves: a two-set form without the moves measured 3 % slower -- code size)
                 if (todo != 0u) {
                     uint32_t c = static_cast<uint32_t>(__builtin_ctz(todo));
                     todo &= todo - 1u;
@@ -1202,43 +1223,29 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 const uint32_t tag = mcache[kLeafTagBase + ls];
                 const uint2 tm = reinterpret_cast<const uint2*>(mcache + kLeafMaskBase)[ls];
                 uint64_t todo;
-                if (__builtin_amdgcn_readfirstlane(tag) == first) {
+                if (__builtin_expect(__builtin_amdgcn_readfirstlane(tag) == first, 1)) {
                     todo = __builtin_amdgcn_readfirstlane(tm.x) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(tm.y)) << 32);
-                } else {  // first visit of this leaf under the current bounds: lane j = triangle j, one coalesced read of the leaf's records
-                    const uint32_t j = threadIdx.x & 63u;
-                    bool keep = false;
-                    if (j < n_real) {
-                        const float* tv = sc.tris_aos + (static_cast<size_t>(first) * 8 + j) * kTriDwords;
-                        const float v0[3] = {tv[0], tv[1], tv[2]}, e1[3] = {tv[3], tv[4], tv[5]}, e2[3] = {tv[6], tv[7], tv[8]};
-                        keep = tri_may_hit(reinterpret_cast<const float*>(mcache), v0, e1, e2);
-                    }
-                    todo = __ballot(keep);
-                    if (j == 0u) {
-                        mcache[kLeafTagBase + ls] = first;
-                        reinterpret_cast<uint2*>(mcache + kLeafMaskBase)[ls] = make_uint2(static_cast<uint32_t>(todo), static_cast<uint32_t>(todo >> 32));
-                    }
+                } else {  // first visit of this leaf under the current bounds
+                    const uint64_t m = leaf_mask_slow(sc.tris_aos, mcache, first, n_real);  // (a call's result is not known to be uniform)
+                    todo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(m)) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(m >> 32))) << 32);
                 }
-                // the surviving triangles, ascending = (packet, lane) order; two register sets alternate: the next survivor's record
-                // is fetched while this one is tested
+                // the surviving triangles, ascending = (packet, lane) order: the next survivor's record is fetched while this one is
+                // tested (one register set rotated through moves: the two-set form measured 3 % slower -- code size)
                 if (todo != 0) {
-                    uint32_t ca = static_cast<uint32_t>(__builtin_ctzll(todo));
+                    uint32_t c = static_cast<uint32_t>(__builtin_ctzll(todo));
                     todo &= todo - 1;
-                    kfp ta = tp + ca * kTriDwords;
+                    kfp ta = tp + c * kTriDwords;
                     float a0 = ta[0], a1 = ta[1], a2 = ta[2], a3 = ta[3], a4 = ta[4], a5 = ta[5], a6 = ta[6], a7 = ta[7], a8 = ta[8];
-                    for (;;) {
-                        if (todo == 0) { test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + ca); break; }
-                        const uint32_t cb = static_cast<uint32_t>(__builtin_ctzll(todo));
+                    while (todo != 0) {
+                        const uint32_t cn = static_cast<uint32_t>(__builtin_ctzll(todo));
                         todo &= todo - 1;
-                        kfp tb = tp + cb * kTriDwords;
+                        kfp tb = tp + cn * kTriDwords;
                         const float b0 = tb[0], b1 = tb[1], b2 = tb[2], b3 = tb[3], b4 = tb[4], b5 = tb[5], b6 = tb[6], b7 = tb[7], b8 = tb[8];
-                        test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + ca);
-                        if (todo == 0) { test(b0, b1, b2, b3, b4, b5, b6, b7, b8, first * 8u + cb); break; }
-                        ca = static_cast<uint32_t>(__builtin_ctzll(todo));
-                        todo &= todo - 1;
-                        ta = tp + ca * kTriDwords;
-                        a0 = ta[0]; a1 = ta[1]; a2 = ta[2]; a3 = ta[3]; a4 = ta[4]; a5 = ta[5]; a6 = ta[6]; a7 = ta[7]; a8 = ta[8];
-                        test(b0, b1, b2, b3, b4, b5, b6, b7, b8, first * 8u + cb);
+                        test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + c);
+                        a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7; a8 = b8;
+                        c = cn;
                     }
+                    test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + c);
                 }
                 if (changed != 0) stale_top = sp;
                 continue;
@@ -1618,7 +1625,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                         trace_packet_objects<(S >= 8 && S <= 32)>(W.scene, r, act, st, h, hinst);
                     }
                 } else {
+#ifdef MP_PROF_NOWALK  // profiling builds only (tools/build_variant.sh): what a pass costs without its walk
+                    const bool go = false;
+#else
                     const bool go = act && W.scene.kind == 0u && may_hit_scene(W.scene, r);
+#endif
                     if (__ballot(go) != 0) {
                         if (LDS_STACK) {
                             HybridStack st(lds, lane, W.scene.stack_cap, W.scene.packet_stack_regs);
@@ -1634,10 +1645,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
             bool hit = h.prim != kNoPrim;
             const RenderParams& H = params_view(KP);  // shading + accumulation
             if (hit) {
+#ifdef MP_PROF_NOSHADE  // profiling builds only
+                c = h.u;
+#else
                 float nn[3];
                 if (OBJ) object_normal(H.scene, hinst, r, h.prim, h.u, h.v, nn);
                 else resolve_normal(H.scene, h.prim, h.u, h.v, nn);
                 c = fabsf(r.dx * nn[0] + r.dy * nn[1] + r.dz * nn[2]);  // worker.rs:60
+#endif
             } else if (H.scene.kind == 1u) {  // Scene<Sphere>
                 float ts_, nn[3];
                 hit = act && sphere_intersect(H.scene, r, ts_, nn);
@@ -1647,7 +1662,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
             {   // (the mask of this pixel's lanes is rebuilt from the lane id here: two registers less across the walk)
                 int l_ = lane;
                 asm volatile("" : "+v"(l_));
-                const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (l_ & ~(S - 1));
+                const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << (S & 63)) - 1ull)) << (l_ & ~(S - 1));
                 cnt += static_cast<float>(__popcll(__ballot(hit) & pixel_lanes));
             }
             add_samples_in_order<S>(acc, c, lane);  // misses add +0.0 (exact)
@@ -2733,8 +2748,8 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
 #ifndef MP_MCACHE_WPE
 #define MP_MCACHE_WPE 8
 #endif
-    // (big scenes only: a teapot packet visits 2.5 nodes per pass, fewer than the per-pass bounds cost -- 12.3 against 11.8 ms)
-    const bool mcache = (L.mask_cache == 2u || (L.mask_cache == 1u && big)) && !lds_stack && !obj && (S == 16 || S == 32) && nspp >= 4u * static_cast<uint32_t>(S) && L.scene.inner_count < (1u << 24) && L.scene.tris_bounded != 0u;
+    // (every scene: with the triangle masks the teapot's frame gains too -- 9.9 against 11.8 ms)
+    const bool mcache = L.mask_cache != 0u && !lds_stack && !obj && (S == 16 || S == 32) && nspp >= 4u * static_cast<uint32_t>(S) && L.scene.inner_count < (1u << 24) && L.scene.tris_bounded != 0u;
     if (mcache) {
         const uint32_t clds = 4u * kMaskCacheDwords * 4u;
         if (S == 32) hipLaunchKernelGGL((render_tiles_packet_kernel<32, false, MP_MCACHE_WPE, false, true>), dim3(grid), dim3(256), clds, st, P);

@@ -171,7 +171,7 @@ struct RenderLaunch {
     bool chunked = false;         // MP_FLAG_CHUNKED_SUM
     uint32_t packet_samples = 0;  // samples of a pixel in flight per pass of the packet kernel (0 = automatic)
     uint32_t rays_per_lane = 1;   // 2: 128-ray walks (render_tiles_packet2_kernel) where applicable
-    uint32_t mask_cache = 1;      // packet kernel: per-unit mask cache of the packet-level child rejection: 0 off, 1 big scenes (auto), 2 always
+    uint32_t mask_cache = 1;      // packet kernel: per-unit mask cache of the packet-level child / triangle rejection: 0 off, 1 / 2 on (units of >= 4 passes)
     uint32_t paths_pooled = 1;    // path extension: 0 = one pass per walk (render_paths_kernel), 1 = pooled passes for big scenes (auto), 2 / 3 = always pooled (two / up to four passes)
     const uint32_t* d_tile_order = nullptr;      // optional: hand-out order of the tiles (device, n_tiles)
     unsigned long long* d_tile_cost = nullptr;   // optional: += shader-clock cycles spent per tile (device, n_tiles)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Frame time of the metric's workload against the samples of a pixel in flight per pass (ctx option packet_samples_in_flight).
-usage: s_sweep.py [atrium|teapot] [spp]   Diagnostics only."""
+usage: s_sweep.py [atrium|teapot] [spp] [packet_mask_cache: 0|1|2]   Diagnostics only."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +10,8 @@ from minipath_amd import scenes
 which = sys.argv[1] if len(sys.argv) > 1 else "atrium"
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 ctx = mp.Context(0)
+if len(sys.argv) > 3:
+    ctx.set_option("packet_mask_cache", int(sys.argv[3]))
 if which == "atrium":
     scene, cam = mp.Scene(mp.TriangleBvh.build(*scenes.atrium(1, 1.0), ctx)), scenes.atrium_camera()
 else:
