@@ -841,6 +841,9 @@ __device__ __forceinline__ uint32_t uniform_u(float f) { return __builtin_amdgcn
 // its t2 = min(hi.x, limit, hi.y, hi.z) <= T2 = min(U.x, U.y, U.z); T1 > T2 therefore means t1 > t2 for every ray whose origin and
 // inverse direction lie in B: the reference pushes the child for none of them (ray_bvh_intersection.rs:158).  No NaN can arise: all
 // inputs are finite, inv is never 0, and B's inverse bounds keep the sign of the pattern.
+#ifndef MP_MC_ONE_STAGE
+#define MP_MC_ONE_STAGE 1  // the cached walk tests a surviving child's three slabs at once (most survivors are pushed: the two-stage exit rarely fires and costs a branch; A/B 25.2 against 25.5 ms)
+#endif
 #ifndef MP_MCACHE_PAD
 #define MP_MCACHE_PAD 0.25f  // widening of the unit's bounds on either side, in extents of the pass that sets them (A/B: 0.0625 .. 1, profiles/r03_notes.md)
 #endif
@@ -1087,7 +1090,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 const uint32_t cl = uniform_u(blink);
                 if (cl == MP_LINK_NULL) return;  // Null links are skipped at pop in the reference (:49)
                 float t1, t2;
-                if (PATCH_NAN) {
+                if (PATCH_NAN || (MC && MP_MC_ONE_STAGE)) {
                     slab<PATCH_NAN, OCT>(b0, b1, b2, b3, b4, b5, r, lim, t1, t2);
                 } else {
                     // aabb.rs:254-284 in two stages (round 3): t1 = max(lo.x, 0, lo.y, lo.z) and t2 = min(hi.x, limit, hi.y, hi.z) are

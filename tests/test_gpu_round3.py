@@ -318,3 +318,42 @@ def test_packet_mask_cache(oracle, teapot_oracle_bvh, mode):
         img, _ = fr.untile()
         torch.cuda.synchronize()
         assert np.array_equal(bits(img.cpu().numpy()), bits(of)), (mode, eye)
+
+
+def test_packet_triangle_masks(oracle):
+    """Round 3: the packet walk's per-unit TRIANGLE masks (tri_may_hit: the Moeller-Trumbore sequence evaluated on intervals over
+    the bounds of a work unit's rays; a triangle no ray inside the bounds can hit is skipped for every pass of the unit).  Frames
+    of the interior stand-in with 8 and 16 passes per unit through a wide lens and a pinhole, and the magnitude guards of the
+    no-overflow argument: a scene scaled beyond 2^30 (DevScene::tris_bounded off: plain walk), a scene within the bound seen from
+    beyond 2^30 (those passes take the plain walk) -- all equal to the oracle bit for bit with the cache on and off."""
+    import ctypes as C
+
+    import torch
+
+    from minipath_amd import scenes
+
+    res = (96, 64)
+    pos, nrm, tex, tri = scenes.atrium(1, 0.08)
+    cases = [(1.0, (-14.0, 4.5, 1.0), (10.0, 5.0, -2.0), 1.4, 256), (1.0, (-14.0, 4.5, 1.0), (10.0, 5.0, -2.0), 1e9, 128),
+             (2.0 ** 31, (-14.0, 4.5, 1.0), (10.0, 5.0, -2.0), 4.0, 64), (2.0 ** 24, (-120.0, 30.0, 9.0), (10.0, 5.0, -2.0), 4.0, 64)]
+    for scale, eye, at, fnum, spp in cases:
+        p = (pos * np.float32(scale)).astype(np.float32)
+        orc = oracle.Bvh.build(p, nrm, tex, tri)
+        oc = oracle.Camera()
+        oracle.lib().mpo_camera_default(C.byref(oc))
+        e = tuple(float(np.float32(x) * np.float32(scale)) for x in eye)
+        a = tuple(float(np.float32(x) * np.float32(scale)) for x in at)
+        oracle.lib().mpo_camera_look_at(C.byref(oc), oracle.vec3(*e), oracle.vec3(*a), oracle.vec3(0, 1, 0))
+        oc.f_number = fnum
+        of, _, _, _, _ = orc.render_image_mt(oracle.build_sampler(oc, *res), res[0], res[1], spp, 21, 32, 8)
+        assert np.count_nonzero(of[..., 3]) > 200  # the view does hit the scene
+        for mode in (1, 0):
+            c = mp.Context(0)
+            c.set_option("packet_mask_cache", mode)
+            scene = mp.Scene(mp.TriangleBvh.build(p, nrm, tex, tri, c))
+            cam = mp.Camera.default().look_at(e, a, (0, 1, 0)).f_number(fnum)
+            fr = mp.FrameRenderer(scene, cam, mp.RenderSettings(32, spp, res, seed=21))
+            fr.render()
+            img, _ = fr.untile()
+            torch.cuda.synchronize()
+            assert np.array_equal(bits(img.cpu().numpy()), bits(of)), (scale, fnum, mode, int(np.sum(bits(img.cpu().numpy()) != bits(of))))
