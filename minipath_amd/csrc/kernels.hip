@@ -708,6 +708,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams) {
 // shared stack live in LDS.
 typedef const __attribute__((address_space(4))) float* kfp;      // constant address space => scalar loads
 typedef const __attribute__((address_space(4))) uint32_t* kup;
+typedef float krec8 __attribute__((ext_vector_type(8)));      // one 32-byte child record
 
 constexpr float kTiny = 9.094947017729282e-13f;  // 2^-40
 constexpr float kHuge = 1099511627776.0f;        // 2^40
@@ -1073,7 +1074,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
         st.pop(sp, link, src, onm);
         if (sp < stale_top) {  // :40-44, per ray (the root is popped first, before anything can be stale)
             stale_top = sp;
-            kfp bx = nodes + static_cast<size_t>(src) * 8;
+            const krec8 bx = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(nodes + static_cast<size_t>(src) * 8);  // one load
             const float node_t1 = slab_entry<PATCH_NAN, OCT>(bx[0], bx[1], bx[2], bx[3], bx[4], bx[5], r);
             onm &= ~mask_gt(node_t1, best_t);
         }
@@ -1148,21 +1149,20 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 }
                 // the surviving children, ascending, through the scalar unit: the next survivor's record is fetched while this one is tested
                 // (one register set rotated through moves: a two-set form without the moves measured 3 % slower -- code size)
+                // (a child record is fetched as ONE 32-byte scalar load -- the compiler splits a 7-dword read into three)
                 if (todo != 0u) {
                     uint32_t c = static_cast<uint32_t>(__builtin_ctz(todo));
                     todo &= todo - 1u;
-                    kfp rc = nd + c * 8u;
-                    float a0 = rc[0], a1 = rc[1], a2 = rc[2], a3 = rc[3], a4 = rc[4], a5 = rc[5], a6 = rc[6];
+                    krec8 ra = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(nd + c * 8u);
                     while (todo != 0u) {
                         const uint32_t cn = static_cast<uint32_t>(__builtin_ctz(todo));
                         todo &= todo - 1u;
-                        kfp rn = nd + cn * 8u;
-                        const float b0 = rn[0], b1 = rn[1], b2 = rn[2], b3 = rn[3], b4 = rn[4], b5 = rn[5], b6 = rn[6];
-                        child(a0, a1, a2, a3, a4, a5, a6, node * 8u + c);
-                        a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6;
+                        const krec8 rb = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(nd + cn * 8u);
+                        child(ra[0], ra[1], ra[2], ra[3], ra[4], ra[5], ra[6], node * 8u + c);
+                        ra = rb;
                         c = cn;
                     }
-                    child(a0, a1, a2, a3, a4, a5, a6, node * 8u + c);
+                    child(ra[0], ra[1], ra[2], ra[3], ra[4], ra[5], ra[6], node * 8u + c);
                 }
                 st.sync(sp);
                 continue;
