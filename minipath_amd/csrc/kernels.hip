@@ -821,6 +821,12 @@ struct HybridStack {
 };
 
 __device__ __forceinline__ uint32_t uniform_u(float f) { return __builtin_amdgcn_readfirstlane(as_u(f)); }
+// a wave-uniform 32-bit value the compiler must not fold into 64-bit address arithmetic (it would leave the scalar unit: v_mad_u64_u32)
+__device__ __forceinline__ uint32_t scalar_u(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+// record i of a leaf whose first record is tp: base + a 32-bit byte offset (s_load's register-offset form: one s_mul_i32)
+__device__ __forceinline__ kfp tri_record(kfp tp, uint32_t i) {
+    return reinterpret_cast<kfp>(reinterpret_cast<const __attribute__((address_space(4))) char*>(tp) + scalar_u(i * static_cast<uint32_t>(kTriDwords * 4)));
+}
 
 // ---- packet-level child rejection with a per-unit mask cache (round 3) ----------------------------------------------------------
 // Counted on the metric's frame (tools/sim_collapse.py --packet-studies; profiles/r03_notes.md): a 64-ray camera packet tests 110
@@ -1237,12 +1243,12 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 if (todo != 0) {
                     uint32_t c = static_cast<uint32_t>(__builtin_ctzll(todo));
                     todo &= todo - 1;
-                    kfp ta = tp + c * kTriDwords;
+                    kfp ta = tri_record(tp, c);
                     float a0 = ta[0], a1 = ta[1], a2 = ta[2], a3 = ta[3], a4 = ta[4], a5 = ta[5], a6 = ta[6], a7 = ta[7], a8 = ta[8];
                     while (todo != 0) {
                         const uint32_t cn = static_cast<uint32_t>(__builtin_ctzll(todo));
                         todo &= todo - 1;
-                        kfp tb = tp + cn * kTriDwords;
+                        kfp tb = tri_record(tp, cn);
                         const float b0 = tb[0], b1 = tb[1], b2 = tb[2], b3 = tb[3], b4 = tb[4], b5 = tb[5], b6 = tb[6], b7 = tb[7], b8 = tb[8];
                         test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + c);
                         a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7; a8 = b8;
@@ -1271,7 +1277,165 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
     hit.t = best_t; hit.u = bu; hit.v = bv; hit.prim = bprim;
 }
 
+// Wave-uniform stack of the cached walk: three VGPRs used as 64-entry arrays (source slot node * 8 + child, and the 64-bit mask of
+// the rays that were live for the parent's visit).
+struct RegStack3 {
+    int src, mlo, mhi;
+    __device__ __forceinline__ RegStack3() : src(0), mlo(0), mhi(0) {}
+    __device__ __forceinline__ void push(int sp, uint32_t s, uint64_t m) {
+        asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                     "v_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0"
+                     : "+v"(src), "+v"(mlo), "+v"(mhi)
+                     : "s"(sp), "s"(s), "s"(static_cast<uint32_t>(m)), "s"(static_cast<uint32_t>(m >> 32))
+                     : "m0");
+    }
+    __device__ __forceinline__ void pop(int sp, uint32_t& s, uint64_t& m) const {
+        s = static_cast<uint32_t>(__builtin_amdgcn_readlane(src, sp));
+        m = static_cast<uint32_t>(__builtin_amdgcn_readlane(mlo, sp)) |
+            (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(mhi, sp))) << 32);
+    }
+};
+
+// The sign-specialised walk of a kernel with a per-unit mask cache (MaskCache, tri_may_hit; `mcache` = this wave's header and
+// entries; every active ray has finite inverse directions of the sign pattern OCT and lies inside the cache's bounds).
+// Same visits, same per-ray decisions as trace_packet_impl<1, OCT>, organised around the cache: a node visit is ONE lookup and
+// pushes the children some ray of the unit may pass WITHOUT testing them; a child's per-ray slab test runs when its entry is
+// popped, against best.t as it is then.  That is the reference's decision: it pushes a child when t1 <= min(hi, best.t at the
+// visit) (:158) and visits it when !(t1 > best.t at the pop) (:40); best.t only shrinks and t1 is never NaN here, so both hold
+// exactly when t1 <= min(hi, best.t at the pop) -- one test with the later limit -- for a ray that was live at the parent's
+// visit (the entry carries that mask: a child box may stick out of its parent's by an ulp).  No entry distance is stored or
+// recomputed, no record is fetched at the visit, and the child's record -- box and link -- is one 32-byte scalar load at the pop.
+template <int OCT>
+__device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ray& r, bool active, PacketHit& hit, uint32_t* mcache) {
+    kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
+    kfp tris = (kfp)(uintptr_t)sc.tris_aos;
+    float best_t = FLT_MAX, bu = 0.0f, bv = 0.0f;  // best (:34-37)
+    uint32_t bprim = kNoPrim;
+    RegStack3 st;
+    st.push(0, kSrcRoot, __ballot(active));  // :28-32 ; the root's t1 = -inf: never culled, never tested
+    int sp = 1;
+    // (fetching the record of the entry that is popped next ahead of its pop -- the last child a visit pushed, the entry below a
+    // leaf -- was built and measured slower: 27.0 against 24.3 ms; eight more live scalar registers and a compare per pop)
+    while (sp > 0) {
+        sp--;
+        uint32_t src;
+        uint64_t pm;  // rays that were live for the parent's visit
+        st.pop(sp, src, pm);
+        const bool pon = __builtin_amdgcn_inverse_ballot_w64(pm);
+        uint32_t link;
+        float lim;  // best.t for the rays this entry is live for, -1 for the others: no slab interval and no hit distance passes
+        if (src == kSrcRoot) {
+            link = sc.root;
+            lim = pon ? best_t : -1.0f;
+        } else {
+            const krec8 rec = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(nodes + static_cast<size_t>(src) * 8);
+            float t1, t2;
+            slab<false, OCT>(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], r, pon ? best_t : -1.0f, t1, t2);  // aabb.rs:254-284
+            const bool ok = t1 <= t2;
+            if (__ballot(ok) == 0) continue;
+            link = uniform_u(rec[6]);
+            lim = ok ? best_t : -1.0f;
+        }
+        if ((link & 63u) == 0u) {  // inner node (device link, mp_internal.h)
+            const uint32_t node = link >> 6;
+            const uint32_t cslot = static_cast<uint32_t>(kMaskCacheHeader) + (node & static_cast<uint32_t>(kMaskCacheEntries - 1));
+            const uint32_t e = __builtin_amdgcn_readfirstlane(mcache[cslot]);
+            uint32_t todo;
+            if (__builtin_expect((e >> 8) == node, 1)) {
+                todo = e & 0xFFu;
+            } else {  // first visit of this node under the current bounds: lane j = child j, records through one vector load pair
+                const int cj = static_cast<int>(threadIdx.x) & 7;
+                bool keep = false;
+                if ((threadIdx.x & 63u) < 8u) {
+                    const float4* rec = reinterpret_cast<const float4*>(sc.nodes_aos) + (static_cast<size_t>(node) * 8 + static_cast<size_t>(cj)) * 2;
+                    const float4 c0 = rec[0], c1 = rec[1];  // {min.xyz, max.x} {max.yz, link, n}
+                    const float bmn[3] = {c0.x, c0.y, c0.z}, bmx[3] = {c0.w, c1.x, c1.y};
+                    keep = as_u(c1.z) != MP_LINK_NULL && bounds_may_hit<OCT>(reinterpret_cast<const float*>(mcache), bmn, bmx);
+                }
+                todo = static_cast<uint32_t>(__ballot(keep)) & 0xFFu;
+                if ((threadIdx.x & 63u) == 0u) mcache[cslot] = (node << 8) | todo;
+            }
+            // children ascending (:161): popped descending.  The entry's mask = the rays live for THIS node
+            const uint64_t nm = __ballot(lim >= 0.0f);
+            while (todo != 0u) {
+                const uint32_t c = static_cast<uint32_t>(__builtin_ctz(todo));
+                todo &= todo - 1u;
+                st.push(sp, node * 8u + c, nm);
+                sp++;
+            }
+        } else {
+            // intersect_triangles :104-140 ; every lane walks the leaf's surviving triangles in (packet, lane) order with a strict `<`
+            const uint32_t first = link >> 6, n_real = link & 63u;
+            kfp tp = tris + static_cast<size_t>(first) * (8 * kTriDwords);
+            const float thr = lim >= 0.0f ? -kTiny : INFINITY;  // early-out threshold: a disabled ray is always "surely rejected"
+            auto test = [&](const float v0x, const float v0y, const float v0z, const float e1x, const float e1y, const float e1z,
+                            const float e2x, const float e2y, const float e2z, const uint32_t tri) {
+                // triangle.rs:183-217 (early-out argument: see trace_packet_impl)
+                const float hx = fms(r.dy, e2z, r.dz * e2y), hy = fms(r.dz, e2x, r.dx * e2z), hz = fms(r.dx, e2y, r.dy * e2x);
+                const float det = fma_dot(e1x, e1y, e1z, hx, hy, hz);
+                const float sx = r.ox - v0x, sy = r.oy - v0y, sz = r.oz - v0z;
+                const float un = fma_dot(sx, sy, sz, hx, hy, hz);
+                const uint32_t det_sign = as_u(det) & 0x80000000u;
+                const bool det_ok = fabsf(det) <= kHuge;
+                const float xu = det_ok ? as_f(as_u(un) ^ det_sign) : 1.0f;
+                if (__ballot(!(xu <= thr)) == 0) return;  // no live ray can have u >= 0
+                const float qx = fms(sy, e1z, sz * e1y), qy = fms(sz, e1x, sx * e1z), qz = fms(sx, e1y, sy * e1x);
+                const float vn = fma_dot(r.dx, r.dy, r.dz, qx, qy, qz);
+                const float tn = fma_dot(e2x, e2y, e2z, qx, qy, qz);
+                const float xv = det_ok ? as_f(as_u(vn) ^ det_sign) : 1.0f, xt = det_ok ? as_f(as_u(tn) ^ det_sign) : 1.0f;
+                if (__ballot(!(fminf(fminf(xu, xv), xt) <= thr)) == 0) return;
+                const float inv_det = 1.0f / det;
+                const float u = inv_det * un, v = inv_det * vn, t = inv_det * tn;
+                const bool acc = (u >= 0.0f) & (v >= 0.0f) & ((u + v) <= 1.0f) & (t >= 0.0f) & (t < lim);  // :125, :129, :59
+                best_t = acc ? t : best_t;
+                lim = acc ? t : lim;
+                bu = acc ? u : bu;
+                bv = acc ? v : bv;
+                bprim = acc ? tri : bprim;
+            };
+            // per-unit triangle masks (see tri_may_hit): which triangles of this leaf can ANY ray inside the unit's bounds hit?
+            const uint32_t ls = first & static_cast<uint32_t>(kLeafCacheEntries - 1);
+            const uint32_t tag = mcache[kLeafTagBase + ls];
+            const uint2 tm = reinterpret_cast<const uint2*>(mcache + kLeafMaskBase)[ls];
+            uint64_t todo;
+            if (__builtin_expect(__builtin_amdgcn_readfirstlane(tag) == first, 1)) {
+                todo = __builtin_amdgcn_readfirstlane(tm.x) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(tm.y)) << 32);
+            } else {  // first visit of this leaf under the current bounds
+                const uint64_t m = leaf_mask_slow(sc.tris_aos, mcache, first, n_real);  // (a call's result is not known to be uniform)
+                todo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(m)) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(m >> 32))) << 32);
+            }
+            // the next survivor's record is fetched while this one is tested (one register set rotated through moves: a two-set
+            // form without the moves measured 3 % slower -- code size)
+            if (todo != 0) {
+                uint32_t c = static_cast<uint32_t>(__builtin_ctzll(todo));
+                todo &= todo - 1;
+                kfp ta = tri_record(tp, c);
+                float a0 = ta[0], a1 = ta[1], a2 = ta[2], a3 = ta[3], a4 = ta[4], a5 = ta[5], a6 = ta[6], a7 = ta[7], a8 = ta[8];
+                while (todo != 0) {
+                    const uint32_t cn = static_cast<uint32_t>(__builtin_ctzll(todo));
+                    todo &= todo - 1;
+                    kfp tb = tri_record(tp, cn);
+                    const float b0 = tb[0], b1 = tb[1], b2 = tb[2], b3 = tb[3], b4 = tb[4], b5 = tb[5], b6 = tb[6], b7 = tb[7], b8 = tb[8];
+                    test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + c);
+                    a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7; a8 = b8;
+                    c = cn;
+                }
+                test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + c);
+            }
+        }
+    }
+    hit.t = best_t; hit.u = bu; hit.v = bv; hit.prim = bprim;
+}
+
 // OCTANTS: also instantiate the eight sign-specialised walks (the production kernels; the rest keep the generic slab).
+#ifndef MP_MC_TEST_AT_POP
+#define MP_MC_TEST_AT_POP 1
+#endif
+#if MP_MC_TEST_AT_POP
+#define MP_MC_WALK(O) trace_packet_cached<O>(sc, r, active, hit, mc.lds)
+#else
+#define MP_MC_WALK(O) trace_packet_impl<1, O, Stack, true>(sc, r, active, st, hit, mc.lds)
+#endif
 template <bool OCTANTS, class Stack, bool MC = false>
 __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit,
                                              const MaskCache& mc = MaskCache{nullptr}) {
@@ -1288,14 +1452,14 @@ __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, b
             if (MC) {  // kernels with a mask cache: the sign-specialised walks use it; a pass with a non-finite component takes the generic walk
                 if (mask_cache_begin_pass(mc, r, active, oct)) {
                     switch (oct) {
-                        case 0: trace_packet_impl<1, 0, Stack, true>(sc, r, active, st, hit, mc.lds); return;
-                        case 1: trace_packet_impl<1, 1, Stack, true>(sc, r, active, st, hit, mc.lds); return;
-                        case 2: trace_packet_impl<1, 2, Stack, true>(sc, r, active, st, hit, mc.lds); return;
-                        case 3: trace_packet_impl<1, 3, Stack, true>(sc, r, active, st, hit, mc.lds); return;
-                        case 4: trace_packet_impl<1, 4, Stack, true>(sc, r, active, st, hit, mc.lds); return;
-                        case 5: trace_packet_impl<1, 5, Stack, true>(sc, r, active, st, hit, mc.lds); return;
-                        case 6: trace_packet_impl<1, 6, Stack, true>(sc, r, active, st, hit, mc.lds); return;
-                        default: trace_packet_impl<1, 7, Stack, true>(sc, r, active, st, hit, mc.lds); return;
+                        case 0: MP_MC_WALK(0); return;
+                        case 1: MP_MC_WALK(1); return;
+                        case 2: MP_MC_WALK(2); return;
+                        case 3: MP_MC_WALK(3); return;
+                        case 4: MP_MC_WALK(4); return;
+                        case 5: MP_MC_WALK(5); return;
+                        case 6: MP_MC_WALK(6); return;
+                        default: MP_MC_WALK(7); return;
                     }
                 }
             } else {
