@@ -152,9 +152,19 @@ int build_device_tree(const HostBvh& h, const std::vector<uint32_t>& pkt_valid, 
         return MP_OK;
     }
     // wide tree, numbered in pre-order (a node's first subtree follows it: the order the walks touch memory in)
+    // The first record of the tail padding (slot count * 8) is the ROOT's: an unbounded box and the root's link, so that a walk
+    // which tests an entry's box when it pops the entry (kernels.hip, trace_packet_cached) needs no special case for the root --
+    // every ray passes an unbounded box with t1 = 0, which is what "the root is never culled" (:28-32) means.
+    auto put_root_record = [&]() {
+        float* rr = &out.nodes[static_cast<size_t>(out.count) * 64];
+        rr[0] = rr[1] = rr[2] = -INFINITY;
+        rr[3] = rr[4] = rr[5] = INFINITY;
+        std::memcpy(&rr[6], &out.root, 4);
+    };
     if (!root_inner) {
         out.nodes.assign(64 + 16, 0.0f);
         out.root = h.root == MP_LINK_NULL ? h.root : leaf_link(h.root);
+        put_root_record();
         return MP_OK;
     }
     // nestable[n]: every real child box of reference node n is ordered and FP-contained in n's own box (the box n's parent
@@ -242,6 +252,7 @@ int build_device_tree(const HostBvh& h, const std::vector<uint32_t>& pkt_valid, 
     }
     out.nodes.resize(static_cast<size_t>(out.count) * 64 + 16, 0.0f);  // tail padding
     out.stack_bound = stack_bound(out.nodes, out.count, out.root);
+    put_root_record();
     return MP_OK;
 }
 

@@ -897,23 +897,27 @@ __device__ __forceinline__ bool mask_cache_begin_pass(const MaskCache& mc, const
     const uint32_t state = __builtin_amdgcn_readfirstlane(mc.lds[12]);
     const bool same = state == (oct | 0x100u);
     const float val[3][3] = {{r.ox, r.oy, r.oz}, {r.ix, r.iy, r.iz}, {r.dx, r.dy, r.dz}};
-    float pmin[3][3], pmax[3][3];  // after the reductions: lane 63 holds the wave's bounds
-    bool viol = !same;             // P inside B ?  (every lane compares its own values with the header; lane 63's are the wave's)
+    // P inside B ?  Every active lane compares its own ray with the header: no reduction in the common case
+    bool viol = !same;
+    if (same) {
 #pragma unroll
-    for (int g = 0; g < 3; g++) {
-        const int base = g == 2 ? 16 : g * 6;
+        for (int g = 0; g < 3; g++) {
+            const int base = g == 2 ? 16 : g * 6;
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            pmin[g][k] = active ? val[g][k] : INFINITY;
-            pmax[g][k] = active ? val[g][k] : -INFINITY;
-        }
-        wave_min3_max3(pmin[g], pmax[g]);
-        if (same) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) viol = viol || pmin[g][k] < hdr[base + k] || pmax[g][k] > hdr[base + 3 + k];
+            for (int k = 0; k < 3; k++) viol = viol || val[g][k] < hdr[base + k] || val[g][k] > hdr[base + 3 + k];
         }
     }
-    if ((__ballot(viol) >> 63) != 0) {
+    if (__ballot(active && viol) != 0) {
+        float pmin[3][3], pmax[3][3];  // after the reductions: lane 63 holds the wave's bounds
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                pmin[g][k] = active ? val[g][k] : INFINITY;
+                pmax[g][k] = active ? val[g][k] : -INFINITY;
+            }
+            wave_min3_max3(pmin[g], pmax[g]);
+        }
         // new bounds: this pass's, united with the old ones when they belong to the same sign pattern, widened by half the extent
         // (an inverse-direction bound never crosses zero: the sign pattern is part of the node masks' meaning; origin bounds stay
         // within 2^31 and direction bounds within 2: every pass that gets here lies well inside)
@@ -1312,7 +1316,7 @@ __device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ra
     float best_t = FLT_MAX, bu = 0.0f, bv = 0.0f;  // best (:34-37)
     uint32_t bprim = kNoPrim;
     RegStack3 st;
-    st.push(0, kSrcRoot, __ballot(active));  // :28-32 ; the root's t1 = -inf: never culled, never tested
+    st.push(0, sc.inner_count * 8u, __ballot(active));  // :28-32 ; the root's record (device_tree.cpp): an unbounded box, never culled
     int sp = 1;
     // (fetching the record of the entry that is popped next ahead of its pop -- the last child a visit pushed, the entry below a
     // leaf -- was built and measured slower: 27.0 against 24.3 ms; eight more live scalar registers and a compare per pop)
@@ -1322,20 +1326,13 @@ __device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ra
         uint64_t pm;  // rays that were live for the parent's visit
         st.pop(sp, src, pm);
         const bool pon = __builtin_amdgcn_inverse_ballot_w64(pm);
-        uint32_t link;
-        float lim;  // best.t for the rays this entry is live for, -1 for the others: no slab interval and no hit distance passes
-        if (src == kSrcRoot) {
-            link = sc.root;
-            lim = pon ? best_t : -1.0f;
-        } else {
-            const krec8 rec = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(nodes + static_cast<size_t>(src) * 8);
-            float t1, t2;
-            slab<false, OCT>(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], r, pon ? best_t : -1.0f, t1, t2);  // aabb.rs:254-284
-            const bool ok = t1 <= t2;
-            if (__ballot(ok) == 0) continue;
-            link = uniform_u(rec[6]);
-            lim = ok ? best_t : -1.0f;
-        }
+        const krec8 rec = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(nodes + static_cast<size_t>(src) * 8);
+        float t1, t2;
+        slab<false, OCT>(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], r, pon ? best_t : -1.0f, t1, t2);  // aabb.rs:254-284
+        const bool ok = t1 <= t2;
+        if (__ballot(ok) == 0) continue;
+        const uint32_t link = uniform_u(rec[6]);
+        float lim = ok ? best_t : -1.0f;  // best.t for the rays this entry is live for, -1 for the others: no slab interval and no hit distance passes
         if ((link & 63u) == 0u) {  // inner node (device link, mp_internal.h)
             const uint32_t node = link >> 6;
             const uint32_t cslot = static_cast<uint32_t>(kMaskCacheHeader) + (node & static_cast<uint32_t>(kMaskCacheEntries - 1));
@@ -1410,17 +1407,19 @@ __device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ra
                 uint32_t c = static_cast<uint32_t>(__builtin_ctzll(todo));
                 todo &= todo - 1;
                 kfp ta = tri_record(tp, c);
-                float a0 = ta[0], a1 = ta[1], a2 = ta[2], a3 = ta[3], a4 = ta[4], a5 = ta[5], a6 = ta[6], a7 = ta[7], a8 = ta[8];
+                krec8 ra = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(ta);  // (one block of eight registers: rotated with 64-bit moves)
+                float a8 = ta[8];
                 while (todo != 0) {
                     const uint32_t cn = static_cast<uint32_t>(__builtin_ctzll(todo));
                     todo &= todo - 1;
                     kfp tb = tri_record(tp, cn);
-                    const float b0 = tb[0], b1 = tb[1], b2 = tb[2], b3 = tb[3], b4 = tb[4], b5 = tb[5], b6 = tb[6], b7 = tb[7], b8 = tb[8];
-                    test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + c);
-                    a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7; a8 = b8;
+                    const krec8 rb = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(tb);
+                    const float b8 = tb[8];
+                    test(ra[0], ra[1], ra[2], ra[3], ra[4], ra[5], ra[6], ra[7], a8, first * 8u + c);
+                    ra = rb; a8 = b8;
                     c = cn;
                 }
-                test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + c);
+                test(ra[0], ra[1], ra[2], ra[3], ra[4], ra[5], ra[6], ra[7], a8, first * 8u + c);
             }
         }
     }
