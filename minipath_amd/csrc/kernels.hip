@@ -1326,7 +1326,8 @@ __device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ra
         uint64_t pm;  // rays that were live for the parent's visit
         st.pop(sp, src, pm);
         const bool pon = __builtin_amdgcn_inverse_ballot_w64(pm);
-        const krec8 rec = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(nodes + static_cast<size_t>(src) * 8);
+        // (base + a 32-bit byte offset: s_load's register-offset form; fewer than 2^24 nodes, checked at launch)
+        const krec8 rec = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(reinterpret_cast<const __attribute__((address_space(4))) char*>(nodes) + scalar_u(src * 32u));
         float t1, t2;
         slab<false, OCT>(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], r, pon ? best_t : -1.0f, t1, t2);  // aabb.rs:254-284
         const bool ok = t1 <= t2;
