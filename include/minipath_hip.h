@@ -209,7 +209,8 @@ int mp_ctx_device(const mp_ctx *ctx, int *device_id, int *cu_count);
  * four passes (2 is kept for callers of earlier builds, where 1 meant big scenes only).  "paths_pooled" (MP_FLAG_PATHS
  * without MP_FLAG_WAVEFRONT; 1 default): 0 = one pass of 8 samples per walk of the bounce rays, 2 / 3 = two / up to four passes share
  * one walk over a per-wave ray queue in global memory (fewer idle lane groups at the end of every walk), 1 = the latter for scenes
- * whose traversal arrays exceed 1 MB.  Results never depend on any of them (tests sweep them). */
+ * whose traversal arrays exceed 1 MB.  "render_batch_tiles" (0 = automatic, default): tiles per launch of mp_render_begin's workers.
+ * Results never depend on any of them (tests sweep them). */
 int mp_ctx_set_option(mp_ctx *ctx, const char *key, int value);
 
 /* ---- camera.rs ------------------------------------------------------------------------------------------ */

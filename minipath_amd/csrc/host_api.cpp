@@ -79,6 +79,7 @@ struct mp_ctx {
     std::atomic<uint32_t> packet_samples{0};  // 0 = chosen by the launcher
     std::atomic<uint32_t> rays_per_lane{1};   // packet kernel: 1 = 64-ray walks, 2 = 128-ray walks (two rays per lane)
     std::atomic<uint32_t> blocks_per_cu{0};   // 0 = as many as fit (diagnostic knob: resident workgroups per CU)
+    std::atomic<uint32_t> render_batch{0};    // tiles per launch of render() (0 = automatic)
     std::atomic<uint32_t> mask_cache{1};      // packet kernel: per-unit mask cache of the packet-level child rejection
     std::atomic<uint32_t> paths_pooled{1};    // path extension: 0 = render_paths_kernel, 1 = auto, 2 / 3 = always pooled (RenderLaunch::paths_pooled)
     uint32_t* take_counter() {  // one set of work-queue heads per launch in flight
@@ -594,6 +595,11 @@ int mp_ctx_set_option(mp_ctx* ctx, const char* key, int value) {
     if (std::strcmp(key, "packet_rays_per_lane") == 0) {
         if (value != 1 && value != 2) return fail(MP_ERR_INVALID, "packet_rays_per_lane must be 1 or 2");
         ctx->rays_per_lane.store(static_cast<uint32_t>(value));
+        return MP_OK;
+    }
+    if (std::strcmp(key, "render_batch_tiles") == 0) {
+        if (value < 0 || value > 65536) return fail(MP_ERR_INVALID, "render_batch_tiles must be in 0..65536 (0 = automatic)");
+        ctx->render_batch.store(static_cast<uint32_t>(value));
         return MP_OK;
     }
     if (std::strcmp(key, "blocks_per_cu") == 0) {
@@ -1507,8 +1513,11 @@ int mp_render_begin_multi(mp_ctx* const* ctxs, const mp_scene* const* scenes, in
     // callbacks keep flowing and that several devices share the queue evenly (the reference hands out one tile per worker).
     const uint32_t ts = settings->tile_size;
     const size_t units_per_tile = static_cast<size_t>((ts + 7) / 8) * ((ts + 7) / 8);
-    size_t batch = std::max<size_t>(1, (static_cast<size_t>(ctxs[0]->cu_count) * 16 + units_per_tile - 1) / units_per_tile);
+    // (round 3: 32 tiles on 256 CUs -- measured on the metric's frame now that its kernel takes 22 ms: 16 / 32 / 64 / 128 / 510 tiles per
+    // launch -> 24.2-26.3 / 24.2-24.5 / 24.8-25.8 / 25.3-26.1 / 28.2-28.8 ms wall; the last batch's readback is not overlapped)
+    size_t batch = std::max<size_t>(1, (static_cast<size_t>(ctxs[0]->cu_count) * 8 + units_per_tile - 1) / units_per_tile);
     if (n > 1) batch = std::max<size_t>(1, std::min(batch, r->tiles.size() / (static_cast<size_t>(n) * 4)));
+    if (ctxs[0]->render_batch.load() != 0) batch = ctxs[0]->render_batch.load();
     r->batch = batch;
     r->start = std::chrono::steady_clock::now();
     r->live_workers.store(n);

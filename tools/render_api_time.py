@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall time of the drop-in render() (async worker thread(s), tile callbacks, host image) against the bare device launch.
-usage: render_api_time.py [teapot|atrium] [contexts]"""
+usage: render_api_time.py [teapot|atrium] [contexts] [render_batch_tiles]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,6 +10,8 @@ from minipath_amd import scenes
 which = sys.argv[1] if len(sys.argv) > 1 else "teapot"
 nctx = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctxs = [mp.Context(0) for _ in range(nctx)]
+if len(sys.argv) > 3:
+    for c in ctxs: c.set_option("render_batch_tiles", int(sys.argv[3]))
 if which == "atrium":
     mesh = scenes.atrium(1, 1.0)
     scs = [mp.Scene(mp.TriangleBvh.build(*mesh, c)) for c in ctxs]
