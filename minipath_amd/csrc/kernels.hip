@@ -2002,11 +2002,18 @@ __device__ __forceinline__ void pixel_state_store3(const RenderParams& P, size_t
 #ifndef MP_PATHS_WPE
 #define MP_PATHS_WPE 6  // waves per SIMD the path kernel's registers are held to (A/B-measured, profiles/r03_notes.md)
 #endif
-template <int S, bool OBJ, bool RGB>
+// MCACHE: the camera pass runs the cached packet walk (MaskCache; the wave's header + tables are the last kMaskCacheDwords dwords of
+// its LDS region)
+template <int S, bool OBJ, bool RGB, bool MCACHE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_PATHS_WPE, 8))) void render_paths_kernel(RenderParams) {
     constexpr int N = RGB ? 3 : 1;
     extern __shared__ __align__(16) unsigned char smem[];
     MP_KERNEL_PARAMS;  // RenderParams through short-lived views (params_view)
+    MaskCache mc{nullptr};
+    if (MCACHE) {
+        const RenderParams& P0 = params_view(KP);
+        mc.lds = reinterpret_cast<uint32_t*>(smem + static_cast<size_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6) + 1) * P0.lds_per_wave) - kMaskCacheDwords;
+    }
     constexpr int BW = (S <= 2) ? 8 : (S <= 8) ? 4 : 2;
     constexpr int BH = 64 / S / BW;
     const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
@@ -2032,6 +2039,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_PATHS_WP
         float acc[N], cnt;  // pixel_sum (r=g=b for a grey table: one channel) and alpha (worker.rs:40)
         if (RGB) pixel_state_load3(P, off, inpix, reinterpret_cast<float (&)[3]>(acc[0]), cnt);
         else pixel_state_load(P, off, inpix, sub == 0, acc[0], cnt);
+        if (MCACHE) {  // a new unit: other pixels, other bounds
+            if (lane == 0) mc.lds[12] = 0xFFFFFFFFu;
+            wave_lds_sync();
+        }
         // passes are aligned to multiples of S in the absolute sample index, so that a chunk boundary (MP_FLAG_CHUNKED_SUM) never
         // falls inside a pass; lanes outside [s_begin, s_end) add +0.0, which is exact
         const uint32_t s_begin = P.s_begin, s_end = P.s_end, max_depth = P.max_depth;
@@ -2075,7 +2086,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_PATHS_WP
                             RegStack rst(nullptr, lane);
                             HybridStack hst(reinterpret_cast<float*>(stack), lane, W.scene.stack_cap, W.scene.packet_stack_regs);
                             if (W.scene.stack_cap > W.scene.packet_stack_regs) trace_packet<false>(W.scene, r, go, hst, h);
-                            else trace_packet<(S >= 8)>(W.scene, r, go, rst, h);
+                            else trace_packet<(S >= 8), RegStack, MCACHE>(W.scene, r, go, rst, h, mc);
                         }
                     } else {
                         // bounce rays: group walk (once per member of an object group)
@@ -2865,6 +2876,16 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
             rc = check(hipGetLastError(), "render_paths_pooled_kernel launch", err);
             (void)hipFreeAsync(P.pool, st);
             return rc;
+        }
+        // camera pass on the cached packet walk (MaskCache): plain scenes whose stack fits the registers, units of at least four
+        // passes, and only while the cache's 3 712 bytes per wave leave the six resident waves per SIMD their LDS
+        const uint32_t clds_wave = P.lds_per_wave + static_cast<uint32_t>(kMaskCacheDwords) * 4u;
+        if (L.mask_cache != 0u && S == 8 && L.scene.inst_count == 0u && L.scene.stack_cap <= L.scene.packet_stack_regs && nspp >= 32u &&
+            L.scene.inner_count < (1u << 24) && L.scene.tris_bounded != 0u && L.scene.boxes_ordered != 0u && clds_wave * 4u * MP_PATHS_WPE <= 160u * 1024u) {
+            P.lds_per_wave = clds_wave;
+            if (rgb) hipLaunchKernelGGL((render_paths_kernel<8, false, true, true>), dim3(grid), dim3(256), clds_wave * 4u, st, P);
+            else hipLaunchKernelGGL((render_paths_kernel<8, false, false, true>), dim3(grid), dim3(256), clds_wave * 4u, st, P);
+            return check(hipGetLastError(), "render_paths_kernel launch", err);
         }
         if (S == 8) MP_LAUNCH_PATHS(8);
         else if (S == 4) MP_LAUNCH_PATHS(4);
