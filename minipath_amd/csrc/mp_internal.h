@@ -60,7 +60,8 @@ int load_obj(const char* path, std::vector<float>& pos, std::vector<float>& nrm,
 // chain, depth and triangle count.
 int bvh_from_arrays(const mp_bvh_desc& d, HostBvh& out, std::string& err);
 
-// Traversal-format node array (device_tree.cpp): `count` nodes x 8 child records x 8 dwords (+ tail padding), the dlink of the
+// Traversal-format node array (device_tree.cpp): `count` nodes x 8 child records x 8 dwords (+ two records of tail padding; in the
+// wide tree the first of them is the ROOT's record: an unbounded box and the root's dlink, slot count * 8), the dlink of the
 // root, the exact traversal-stack bound and whether every real child box has min <= max.  wide = thin nodes absorbed into
 // their parents (the tree the walks use for rays with finite inverse directions); otherwise the literal reference tree.
 struct DeviceTree {
