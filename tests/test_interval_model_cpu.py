@@ -29,3 +29,43 @@ def test_interval_rejection_is_conservative():
                 rejected += int(rej.sum()); hit += int(some.sum()); wrong += int((rej & some).sum())
     assert wrong == 0
     assert hit > 0 and rejected > 10 * hit  # the test sees hits, and the bounds reject most of the rest
+
+
+def test_interval_rejection_of_child_boxes_is_conservative():
+    """... and the node masks (kernels.hip, bounds_may_hit): a child box the bounds reject is passed by no ray inside them."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sim_tri_reject as st
+    from sim_collapse import RefTree, build_device, load, slab
+
+    F = np.float32
+    ref = RefTree(*load("teapot", 1.0))
+    nodes, _, _ = build_device(ref, "area", 8)
+    rng = np.random.default_rng(9)
+    rejected = passed = wrong = 0
+    for o, d in st.camera_packets("teapot", 8, rng, 2, w=192, h=108):
+        with np.errstate(divide="ignore"):
+            inv = np.where(d == 0, F(np.inf), F(1) / d).astype(F)
+        if not np.isfinite(inv).all() or any((np.sign(inv[:, k]) != np.sign(inv[0, k])).any() for k in range(3)):
+            continue  # the device takes the plain walk for such a pass
+        sg = np.sign(inv[0])
+        for pad in (0.0, 0.25):
+            eo, ei = (o.max(0) - o.min(0)) * F(pad), (inv.max(0) - inv.min(0)) * F(pad)
+            omin, omax = (o.min(0) - eo).astype(F), (o.max(0) + eo).astype(F)
+            imin, imax = (inv.min(0) - ei).astype(F), (inv.max(0) + ei).astype(F)
+            for k in range(3):  # an inverse-direction bound never crosses zero (mask_cache_begin_pass)
+                if np.sign(imin[k]) != sg[k] or imin[k] == 0: imin[k] = inv[:, k].min()
+                if np.sign(imax[k]) != sg[k] or imax[k] == 0: imax[k] = inv[:, k].max()
+            for boxes, _links in nodes:
+                t1, t2 = slab(boxes, o, inv, np.full(64, np.finfo(F).max, F))
+                some = (t1 <= t2).any(axis=0)
+                L, U = [], []
+                for k in range(3):
+                    y, z = (boxes[:, k] - omax[k]).astype(F), (boxes[:, 3 + k] - omin[k]).astype(F)
+                    lo_src, hi_src = (y, z) if sg[k] > 0 else (z, y)
+                    L.append(np.minimum(lo_src * imin[k], lo_src * imax[k]).astype(F))
+                    U.append(np.maximum(hi_src * imin[k], hi_src * imax[k]).astype(F))
+                T1 = np.maximum(np.maximum(L[0], F(0)), np.maximum(L[1], L[2])); T2 = np.minimum(U[0], np.minimum(U[1], U[2]))
+                rej = T1 > T2
+                rejected += int(rej.sum()); passed += int(some.sum()); wrong += int((rej & some).sum())
+    assert wrong == 0
+    assert passed > 0 and rejected > 0
