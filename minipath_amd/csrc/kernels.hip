@@ -848,9 +848,6 @@ __device__ __forceinline__ kfp tri_record(kfp tp, uint32_t i) {
 // its t2 = min(hi.x, limit, hi.y, hi.z) <= T2 = min(U.x, U.y, U.z); T1 > T2 therefore means t1 > t2 for every ray whose origin and
 // inverse direction lie in B: the reference pushes the child for none of them (ray_bvh_intersection.rs:158).  No NaN can arise: all
 // inputs are finite, inv is never 0, and B's inverse bounds keep the sign of the pattern.
-#ifndef MP_MC_ONE_STAGE
-#define MP_MC_ONE_STAGE 1  // the cached walk tests a surviving child's three slabs at once (most survivors are pushed: the two-stage exit rarely fires and costs a branch; A/B 25.2 against 25.5 ms)
-#endif
 #ifndef MP_MCACHE_PAD
 #define MP_MCACHE_PAD 0.25f  // widening of the unit's bounds on either side, in extents of the pass that sets them (A/B: 0.0625 .. 1, profiles/r03_notes.md)
 #endif
@@ -1061,10 +1058,8 @@ __device__ __noinline__ uint64_t leaf_mask_slow(const float* __restrict__ tris_a
 // +inf: a disabled ray is always "surely rejected") -- so every ballot below is already the masked result and "no ray left" is a
 // branch on VCC; det's magnitude guard is a v_cndmask, the three sign tests one minNum chain; loops are single-exit pair loops
 // with a scalar countdown; pushes are v_writelane; staleness is a low-water mark instead of a 64-bit mask.
-// MC: the sign-specialised walk consults the per-unit mask cache `mcache` (never null then) instead of testing every child
-template <int MODE, int OCT, class Stack, bool MC = false>
-__device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit,
-                                                  uint32_t* mcache = nullptr) {
+template <int MODE, int OCT, class Stack>
+__device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit) {
     constexpr bool PATCH_NAN = MODE == 2;
     // MODE 2 walks the literal reference tree, MODE 1 the wide tree (thin nodes absorbed into their parents: bit-identical hits
     // for rays with finite inverse directions, device_tree.cpp)
@@ -1101,7 +1096,7 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 const uint32_t cl = uniform_u(blink);
                 if (cl == MP_LINK_NULL) return;  // Null links are skipped at pop in the reference (:49)
                 float t1, t2;
-                if (PATCH_NAN || (MC && MP_MC_ONE_STAGE)) {
+                if (PATCH_NAN) {
                     slab<PATCH_NAN, OCT>(b0, b1, b2, b3, b4, b5, r, lim, t1, t2);
                 } else {
                     // aabb.rs:254-284 in two stages (round 3): t1 = max(lo.x, 0, lo.y, lo.z) and t2 = min(hi.x, limit, hi.y, hi.z) are
@@ -1138,45 +1133,6 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                     sp++;
                 }
             };
-            if (MC && OCT >= 0) {
-                // per-unit mask cache (see MaskCache): which children can ANY ray inside the unit's bounds pass?
-                const uint32_t cslot = static_cast<uint32_t>(kMaskCacheHeader) + (node & static_cast<uint32_t>(kMaskCacheEntries - 1));
-                const uint32_t e = __builtin_amdgcn_readfirstlane(mcache[cslot]);
-                uint32_t todo;
-                if (__builtin_expect((e >> 8) == node, 1)) {
-                    todo = e & 0xFFu;
-                } else {  // first visit of this node under the current bounds: lane j = child j, records through one vector load pair
-                    const int cj = static_cast<int>(threadIdx.x) & 7;
-                    bool keep = false;
-                    if ((threadIdx.x & 63u) < 8u) {
-                        const float4* rec = reinterpret_cast<const float4*>(sc.nodes_aos) + (static_cast<size_t>(node) * 8 + static_cast<size_t>(cj)) * 2;
-                        const float4 c0 = rec[0], c1 = rec[1];  // {min.xyz, max.x} {max.yz, link, n}
-                        const float bmn[3] = {c0.x, c0.y, c0.z}, bmx[3] = {c0.w, c1.x, c1.y};
-                        keep = as_u(c1.z) != MP_LINK_NULL && bounds_may_hit<OCT>(reinterpret_cast<const float*>(mcache), bmn, bmx);
-                    }
-                    todo = static_cast<uint32_t>(__ballot(keep)) & 0xFFu;
-                    if ((threadIdx.x & 63u) == 0u) mcache[cslot] = (node << 8) | todo;
-                }
-                // the surviving children, ascending, through the scalar unit: the next survivor's record is fetched while this one is tested
-                // (one register set rotated through moves: a two-set form without the moves measured 3 % slower -- code size)
-                // (a child record is fetched as ONE 32-byte scalar load -- the compiler splits a 7-dword read into three)
-                if (todo != 0u) {
-                    uint32_t c = static_cast<uint32_t>(__builtin_ctz(todo));
-                    todo &= todo - 1u;
-                    krec8 ra = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(nd + c * 8u);
-                    while (todo != 0u) {
-                        const uint32_t cn = static_cast<uint32_t>(__builtin_ctz(todo));
-                        todo &= todo - 1u;
-                        const krec8 rb = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(nd + cn * 8u);
-                        child(ra[0], ra[1], ra[2], ra[3], ra[4], ra[5], ra[6], node * 8u + c);
-                        ra = rb;
-                        c = cn;
-                    }
-                    child(ra[0], ra[1], ra[2], ra[3], ra[4], ra[5], ra[6], node * 8u + c);
-                }
-                st.sync(sp);
-                continue;
-            }
             float a0 = nd[0], a1 = nd[1], a2 = nd[2], a3 = nd[3], a4 = nd[4], a5 = nd[5], a6 = nd[6];
             const uint32_t nchild = uniform_u(nd[7]);
             uint32_t slot = node * 8u;
@@ -1230,39 +1186,6 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
                 bprim = acc ? tri : bprim;
                 changed |= __ballot(acc);
             };
-            if (MC && OCT >= 0) {
-                // per-unit triangle masks (see tri_may_hit): which triangles of this leaf can ANY ray inside the unit's bounds hit?
-                const uint32_t ls = first & static_cast<uint32_t>(kLeafCacheEntries - 1);
-                const uint32_t tag = mcache[kLeafTagBase + ls];
-                const uint2 tm = reinterpret_cast<const uint2*>(mcache + kLeafMaskBase)[ls];
-                uint64_t todo;
-                if (__builtin_expect(__builtin_amdgcn_readfirstlane(tag) == first, 1)) {
-                    todo = __builtin_amdgcn_readfirstlane(tm.x) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(tm.y)) << 32);
-                } else {  // first visit of this leaf under the current bounds
-                    const uint64_t m = leaf_mask_slow(sc.tris_aos, mcache, first, n_real);  // (a call's result is not known to be uniform)
-                    todo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(m)) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(m >> 32))) << 32);
-                }
-                // the surviving triangles, ascending = (packet, lane) order: the next survivor's record is fetched while this one is
-                // tested (one register set rotated through moves: the two-set form measured 3 % slower -- code size)
-                if (todo != 0) {
-                    uint32_t c = static_cast<uint32_t>(__builtin_ctzll(todo));
-                    todo &= todo - 1;
-                    kfp ta = tri_record(tp, c);
-                    float a0 = ta[0], a1 = ta[1], a2 = ta[2], a3 = ta[3], a4 = ta[4], a5 = ta[5], a6 = ta[6], a7 = ta[7], a8 = ta[8];
-                    while (todo != 0) {
-                        const uint32_t cn = static_cast<uint32_t>(__builtin_ctzll(todo));
-                        todo &= todo - 1;
-                        kfp tb = tri_record(tp, cn);
-                        const float b0 = tb[0], b1 = tb[1], b2 = tb[2], b3 = tb[3], b4 = tb[4], b5 = tb[5], b6 = tb[6], b7 = tb[7], b8 = tb[8];
-                        test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + c);
-                        a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7; a8 = b8;
-                        c = cn;
-                    }
-                    test(a0, a1, a2, a3, a4, a5, a6, a7, a8, first * 8u + c);
-                }
-                if (changed != 0) stale_top = sp;
-                continue;
-            }
             // two register sets (A, B) alternate: B is fetched while A is tested and vice versa (the array has tail padding)
             float a0 = tp[0], a1 = tp[1], a2 = tp[2], a3 = tp[3], a4 = tp[4], a5 = tp[5], a6 = tp[6], a7 = tp[7], a8 = tp[8];
             uint32_t tri = first * 8u;
@@ -1428,14 +1351,6 @@ __device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ra
 }
 
 // OCTANTS: also instantiate the eight sign-specialised walks (the production kernels; the rest keep the generic slab).
-#ifndef MP_MC_TEST_AT_POP
-#define MP_MC_TEST_AT_POP 1
-#endif
-#if MP_MC_TEST_AT_POP
-#define MP_MC_WALK(O) trace_packet_cached<O>(sc, r, active, hit, mc.lds)
-#else
-#define MP_MC_WALK(O) trace_packet_impl<1, O, Stack, true>(sc, r, active, st, hit, mc.lds)
-#endif
 template <bool OCTANTS, class Stack, bool MC = false>
 __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, bool active, Stack& st, PacketHit& hit,
                                              const MaskCache& mc = MaskCache{nullptr}) {
@@ -1452,14 +1367,14 @@ __device__ __forceinline__ void trace_packet(const DevScene& sc, const Ray& r, b
             if (MC) {  // kernels with a mask cache: the sign-specialised walks use it; a pass with a non-finite component takes the generic walk
                 if (mask_cache_begin_pass(mc, r, active, oct)) {
                     switch (oct) {
-                        case 0: MP_MC_WALK(0); return;
-                        case 1: MP_MC_WALK(1); return;
-                        case 2: MP_MC_WALK(2); return;
-                        case 3: MP_MC_WALK(3); return;
-                        case 4: MP_MC_WALK(4); return;
-                        case 5: MP_MC_WALK(5); return;
-                        case 6: MP_MC_WALK(6); return;
-                        default: MP_MC_WALK(7); return;
+                        case 0: trace_packet_cached<0>(sc, r, active, hit, mc.lds); return;
+                        case 1: trace_packet_cached<1>(sc, r, active, hit, mc.lds); return;
+                        case 2: trace_packet_cached<2>(sc, r, active, hit, mc.lds); return;
+                        case 3: trace_packet_cached<3>(sc, r, active, hit, mc.lds); return;
+                        case 4: trace_packet_cached<4>(sc, r, active, hit, mc.lds); return;
+                        case 5: trace_packet_cached<5>(sc, r, active, hit, mc.lds); return;
+                        case 6: trace_packet_cached<6>(sc, r, active, hit, mc.lds); return;
+                        default: trace_packet_cached<7>(sc, r, active, hit, mc.lds); return;
                     }
                 }
             } else {
