@@ -1718,7 +1718,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                             trace_packet<false>(W.scene, r, go, st, h);
                         } else {
                             RegStack st(lds, lane);
-                            trace_packet<(S >= 8 && S <= 32), RegStack, MCACHE>(W.scene, r, go, st, h, mc);
+                            trace_packet<((S >= 8 && S <= 32) || MCACHE), RegStack, MCACHE>(W.scene, r, go, st, h, mc);
                         }
                     }
                 }
@@ -2820,15 +2820,22 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
     const uint32_t nspp = L.pass_end - L.pass_begin;  // samples per pixel in this launch
     int S = nspp >= 16 ? 16 : nspp >= 8 ? 8 : nspp >= 4 ? 4 : nspp >= 2 ? 2 : 1;
     // small launches (a rank's shard of a multi-GPU frame): 2-pixel units, so that the tail of the launch is half as long
-    if (nspp >= 32 && units * 16u < static_cast<uint64_t>(L.cu_count) * 32u * 24u) S = 32;
+    const bool small_launch = units * 16u < static_cast<uint64_t>(L.cu_count) * 32u * 24u;
+    if (nspp >= 32 && small_launch) S = 32;
     // scenes whose traversal arrays exceed the 16 KB scalar data cache by far run 8 waves per SIMD, and at many samples per pixel
     // 32 samples of a pixel in flight (a 1x2 pixel footprint: measured 42.1 against 42.6 ms on the metric's frame, tools/s_sweep.py)
     const bool big = (static_cast<uint64_t>(L.scene.inner_count) * 256u + static_cast<uint64_t>(L.scene.packet_count) * 384u) > (1u << 20);
     if (big && nspp >= 128) S = 32;
-    if (L.packet_samples) S = static_cast<int>(std::min<uint32_t>(L.packet_samples, 64u));
     const bool obj = L.scene.inst_count != 0u;  // object group: one packet walk per member (instantiated for 16 and 1 samples in flight)
-    if (obj) S = (S >= 16 && nspp >= 16) ? 16 : 1;
     const bool lds_stack = L.scene.stack_cap > L.scene.packet_stack_regs;
+    // The per-unit mask cache (MaskCache) wants units of at least four passes: with it, the samples in flight follow the sample
+    // count -- 16 from 64 spp on (metric's frame, 256 spp: 21.7 ms against 22.1 with 32; 64 spp: 6.3 against 6.4 with 8), 8 for
+    // 32-63 spp (3.5 against 5.5 ms uncached at 32 spp), 4 for 16-31 (2.2 against 2.9 ms at 16 spp) -- and small launches keep
+    // their 2-pixel units where those still have four passes
+    const bool cache_ok = L.mask_cache != 0u && !lds_stack && !obj && L.scene.kind == 0u && L.scene.inner_count < (1u << 24) && L.scene.tris_bounded != 0u;
+    if (cache_ok && nspp >= 16) S = (small_launch && nspp >= 128) ? 32 : nspp >= 64 ? 16 : nspp >= 32 ? 8 : 4;
+    if (L.packet_samples) S = static_cast<int>(std::min<uint32_t>(L.packet_samples, 64u));
+    if (obj) S = (S >= 16 && nspp >= 16) ? 16 : 1;
     P.lds_per_wave = lds_stack ? (L.scene.stack_cap - L.scene.packet_stack_regs) * 16u : 0u;  // one uint4 per entry beyond the register stack
     const uint32_t plds = P.lds_per_wave * 4;
     if (plds > 160 * 1024) { err = "scene too deep for the LDS traversal stack"; return MP_ERR_UNSUPPORTED; }
@@ -2852,10 +2859,12 @@ int launch_render_tiles(const RenderLaunch& L, void* stream, std::string& err) {
 #define MP_MCACHE_WPE 8
 #endif
     // (every scene: with the triangle masks the teapot's frame gains too -- 9.9 against 11.8 ms)
-    const bool mcache = L.mask_cache != 0u && !lds_stack && !obj && (S == 16 || S == 32) && nspp >= 4u * static_cast<uint32_t>(S) && L.scene.inner_count < (1u << 24) && L.scene.tris_bounded != 0u;
+    const bool mcache = cache_ok && (S == 4 || S == 8 || S == 16 || S == 32) && nspp >= 4u * static_cast<uint32_t>(S);
     if (mcache) {
         const uint32_t clds = 4u * kMaskCacheDwords * 4u;
         if (S == 32) hipLaunchKernelGGL((render_tiles_packet_kernel<32, false, MP_MCACHE_WPE, false, true>), dim3(grid), dim3(256), clds, st, P);
+        else if (S == 8) hipLaunchKernelGGL((render_tiles_packet_kernel<8, false, MP_MCACHE_WPE, false, true>), dim3(grid), dim3(256), clds, st, P);
+        else if (S == 4) hipLaunchKernelGGL((render_tiles_packet_kernel<4, false, MP_MCACHE_WPE, false, true>), dim3(grid), dim3(256), clds, st, P);
         else hipLaunchKernelGGL((render_tiles_packet_kernel<16, false, MP_MCACHE_WPE, false, true>), dim3(grid), dim3(256), clds, st, P);
         return check(hipGetLastError(), "render_tiles_packet_kernel launch", err);
     }
