@@ -115,8 +115,10 @@ std::vector<uint32_t> packet_real_counts(const HostBvh& h) {
 
 int build_device_tree(const HostBvh& h, const std::vector<uint32_t>& pkt_valid, bool wide, DeviceTree& out, std::string& err) {
     const size_t ni = h.inner.size(), np = h.packets.size();
-    if (np >= (1u << 26) - 1u || ni >= (1u << 26)) {
-        err = "scene too large for the device link format (2^26-2 packets)";
+    // device links hold 26 bits of index; the 8-lane-group walk and the cached packet walk address records as a base + a 32-bit byte
+    // offset (288 bytes per packet, 256 per node)
+    if (np >= (1u << 26) - 1u || ni >= (1u << 24) || static_cast<uint64_t>(np) * 288u >= (1ull << 32)) {
+        err = "scene too large for the device traversal format (2^24 nodes, 2^32 bytes of triangle records = 14.9 M packets)";
         return MP_ERR_UNSUPPORTED;
     }
     // device link (mp_internal.h): leaf = first packet << 6 | real triangles ; null unchanged ; inner = device node index << 6

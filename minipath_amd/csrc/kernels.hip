@@ -276,7 +276,8 @@ __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __res
                 if ((link & 63u) == 0u) {  // device link (mp_internal.h): inner = index << 6
                     // InnerNode::intersect :149-162 ; lane li = child li.  Child boxes are stored decompressed
                     // (SURVEY A.4 box chain evaluated once on the host), so the slab test starts directly.
-                    const float4* cp = nodes4 + (static_cast<size_t>(link >> 6) * 8 + li) * 2;
+                    // (a uniform base + a 32-bit byte offset per lane: link = node << 6, a node is 256 bytes, a child record 32)
+                    const float4* cp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes4) + ((link << 2) | (static_cast<uint32_t>(li) << 5)));
                     const float4 c0 = cp[0], c1 = cp[1];  // {min.xyz, max.x} {max.yz, link, -}
                     const uint32_t child = as_u(c1.z);
                     // aabb.rs:254-284
@@ -308,7 +309,9 @@ __device__ __forceinline__ void trace_wave_impl(const DevScene& sc, float* __res
         }
         // -- B: one leaf packet per iteration (:104-140) ; lane li = triangle li
         if (slot >= 0 && pk < pk_end) {
-            const float* tp = tris + (static_cast<size_t>(pk) * 8 + li) * kTriDwords;  // 36-byte records: v0, e1, e2
+            // 36-byte records: v0, e1, e2 ; a uniform base + a 32-bit byte offset per lane (fewer than 2^32 / 288 packets: upload_scene)
+            const uint32_t toff = ((pk * 9u) << 5) + static_cast<uint32_t>(li) * 36u;
+            const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(tris) + toff);
             const float v0x = tp[0], v0y = tp[1], v0z = tp[2], e1x = tp[3], e1y = tp[4], e1z = tp[5], e2x = tp[6], e2y = tp[7], e2z = tp[8];
             // triangle.rs:183-217
             float hx = fms(dy, e2z, dz * e2y), hy = fms(dz, e2x, dx * e2z), hz = fms(dx, e2y, dy * e2x);

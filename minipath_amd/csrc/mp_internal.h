@@ -82,7 +82,8 @@ int build_device_tree(const HostBvh& h, const std::vector<uint32_t>& pkt_valid, 
 //             the literal reference tree in the same format, walked by rays with an infinite inverse direction component.
 // dlink     : device-private link (the reference's CompressedNodeLink idx<<3|count, mod.rs:57-114, re-encoded so that a leaf needs
 //             no side lookup): inner = node index << 6 ; leaf = first packet << 6 | real (unpadded) triangles of the leaf (1..56) ;
-//             null = MP_LINK_NULL unchanged (checked before decoding; scenes are limited to 2^26-2 packets).
+//             null = MP_LINK_NULL unchanged (checked before decoding; scenes are limited to 2^24 nodes and 14.9 M packets:
+//             the walks address records with 32-bit byte offsets).
 // tris_aos  : packet_count x 8 triangles x kTriDwords (9) dwords {v0.xyz,e1.xyz,e2.xyz}: decompressed v0 and the edges e1=v1-v0,
 //             e2=v2-v0 of triangle.rs:195-196 (+ 3 records of tail padding: the packet walk fetches two triangles ahead).
 //             The packet walk reads both through the scalar unit (wave-uniform), the 8-lane-group walk with per-lane vector loads
