@@ -1207,20 +1207,22 @@ __device__ __forceinline__ void trace_packet_impl(const DevScene& sc, const Ray&
     hit.t = best_t; hit.u = bu; hit.v = bv; hit.prim = bprim;
 }
 
-// Wave-uniform stack of the cached walk: three VGPRs used as 64-entry arrays (source slot node * 8 + child, and the 64-bit mask of
-// the rays that were live for the parent's visit).
+// Wave-uniform stack of the cached walk: three VGPRs used as 64-entry arrays.  An entry is a FRAME -- a visited node with the children
+// that are still to be popped (node << 8 | 8-bit mask) and the 64-bit mask of the rays that were live at the visit.  The frame on
+// top lives in scalar registers: popping a child is three scalar instructions, and the arrays are touched once per node visit
+// instead of once per child.
 struct RegStack3 {
-    int src, mlo, mhi;
-    __device__ __forceinline__ RegStack3() : src(0), mlo(0), mhi(0) {}
-    __device__ __forceinline__ void push(int sp, uint32_t s, uint64_t m) {
+    int ent, mlo, mhi;
+    __device__ __forceinline__ RegStack3() : ent(0), mlo(0), mhi(0) {}
+    __device__ __forceinline__ void push(int sp, uint32_t e, uint64_t m) {
         asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\t"
                      "v_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0"
-                     : "+v"(src), "+v"(mlo), "+v"(mhi)
-                     : "s"(sp), "s"(s), "s"(static_cast<uint32_t>(m)), "s"(static_cast<uint32_t>(m >> 32))
+                     : "+v"(ent), "+v"(mlo), "+v"(mhi)
+                     : "s"(sp), "s"(e), "s"(static_cast<uint32_t>(m)), "s"(static_cast<uint32_t>(m >> 32))
                      : "m0");
     }
-    __device__ __forceinline__ void pop(int sp, uint32_t& s, uint64_t& m) const {
-        s = static_cast<uint32_t>(__builtin_amdgcn_readlane(src, sp));
+    __device__ __forceinline__ void pop(int sp, uint32_t& e, uint64_t& m) const {
+        e = static_cast<uint32_t>(__builtin_amdgcn_readlane(ent, sp));
         m = static_cast<uint32_t>(__builtin_amdgcn_readlane(mlo, sp)) |
             (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(mhi, sp))) << 32);
     }
@@ -1229,12 +1231,14 @@ struct RegStack3 {
 // The sign-specialised walk of a kernel with a per-unit mask cache (MaskCache, tri_may_hit; `mcache` = this wave's header and
 // entries; every active ray has finite inverse directions of the sign pattern OCT and lies inside the cache's bounds).
 // Same visits, same per-ray decisions as trace_packet_impl<1, OCT>, organised around the cache: a node visit is ONE lookup and
-// pushes the children some ray of the unit may pass WITHOUT testing them; a child's per-ray slab test runs when its entry is
-// popped, against best.t as it is then.  That is the reference's decision: it pushes a child when t1 <= min(hi, best.t at the
-// visit) (:158) and visits it when !(t1 > best.t at the pop) (:40); best.t only shrinks and t1 is never NaN here, so both hold
-// exactly when t1 <= min(hi, best.t at the pop) -- one test with the later limit -- for a ray that was live at the parent's
-// visit (the entry carries that mask: a child box may stick out of its parent's by an ulp).  No entry distance is stored or
-// recomputed, no record is fetched at the visit, and the child's record -- box and link -- is one 32-byte scalar load at the pop.
+// opens a frame with the children some ray of the unit may pass, WITHOUT testing them; a child's per-ray slab test runs when it is
+// popped from its frame (highest index first: the reference pushes ascending and pops descending, :161), against best.t as it is
+// then.  That is the reference's decision: it pushes a child when t1 <= min(hi, best.t at the visit) (:158) and visits it when
+// !(t1 > best.t at the pop) (:40); best.t only shrinks and t1 is never NaN here, so both hold exactly when t1 <= min(hi, best.t
+// at the pop) -- one test with the later limit -- for a ray that was live at the parent's visit (the frame carries that mask: a
+// child box may stick out of its parent's by an ulp).  No entry distance is stored or recomputed, no record is fetched at the
+// visit, and the child's record -- box and link -- is one 32-byte scalar load at the pop.  The root is child 0 of a pseudo-node
+// behind the last node: its record (device_tree.cpp) is an unbounded box, which every ray passes with t1 = 0 -- never culled (:28-32).
 template <int OCT>
 __device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ray& r, bool active, PacketHit& hit, uint32_t* mcache) {
     kfp nodes = (kfp)(uintptr_t)sc.nodes_aos;
@@ -1242,24 +1246,28 @@ __device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ra
     float best_t = FLT_MAX, bu = 0.0f, bv = 0.0f;  // best (:34-37)
     uint32_t bprim = kNoPrim;
     RegStack3 st;
-    st.push(0, sc.inner_count * 8u, __ballot(active));  // :28-32 ; the root's record (device_tree.cpp): an unbounded box, never culled
-    int sp = 1;
-    // (fetching the record of the entry that is popped next ahead of its pop -- the last child a visit pushed, the entry below a
-    // leaf -- was built and measured slower: 27.0 against 24.3 ms; eight more live scalar registers and a compare per pop)
-    while (sp > 0) {
-        sp--;
-        uint32_t src;
-        uint64_t pm;  // rays that were live for the parent's visit
-        st.pop(sp, src, pm);
+    int sp = 0;                                   // frames below the current one
+    uint32_t cur = (sc.inner_count << 8) | 1u;    // current frame: node << 8 | children still to pop
+    uint64_t pm = __ballot(active);               // ... and the rays that were live at its visit
+    // (fetching the record of the child that is popped next ahead of its pop was built and measured slower: 27.0 against 24.3 ms)
+    for (;;) {
+        if ((cur & 0xFFu) == 0u) {  // frame exhausted: back to the one below
+            if (sp == 0) break;
+            sp--;
+            st.pop(sp, cur, pm);
+        }
+        const uint32_t c = 31u - static_cast<uint32_t>(__builtin_clz(cur & 0xFFu));  // highest child first
+        cur &= ~(1u << c);
+        const uint32_t src = ((cur >> 8) << 3) | c;
         const bool pon = __builtin_amdgcn_inverse_ballot_w64(pm);
-        // (base + a 32-bit byte offset: s_load's register-offset form; fewer than 2^24 nodes, checked at launch)
+        // (base + a 32-bit byte offset: s_load's register-offset form; fewer than 2^24 nodes, checked at upload)
         const krec8 rec = *reinterpret_cast<const __attribute__((address_space(4))) krec8*>(reinterpret_cast<const __attribute__((address_space(4))) char*>(nodes) + scalar_u(src * 32u));
         float t1, t2;
         slab<false, OCT>(rec[0], rec[1], rec[2], rec[3], rec[4], rec[5], r, pon ? best_t : -1.0f, t1, t2);  // aabb.rs:254-284
         const bool ok = t1 <= t2;
         if (__ballot(ok) == 0) continue;
         const uint32_t link = uniform_u(rec[6]);
-        float lim = ok ? best_t : -1.0f;  // best.t for the rays this entry is live for, -1 for the others: no slab interval and no hit distance passes
+        float lim = ok ? best_t : -1.0f;  // best.t for the rays this child is live for, -1 for the others: no slab interval and no hit distance passes
         if ((link & 63u) == 0u) {  // inner node (device link, mp_internal.h)
             const uint32_t node = link >> 6;
             const uint32_t cslot = static_cast<uint32_t>(kMaskCacheHeader) + (node & static_cast<uint32_t>(kMaskCacheEntries - 1));
@@ -1271,21 +1279,21 @@ __device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ra
                 const int cj = static_cast<int>(threadIdx.x) & 7;
                 bool keep = false;
                 if ((threadIdx.x & 63u) < 8u) {
-                    const float4* rec = reinterpret_cast<const float4*>(sc.nodes_aos) + (static_cast<size_t>(node) * 8 + static_cast<size_t>(cj)) * 2;
-                    const float4 c0 = rec[0], c1 = rec[1];  // {min.xyz, max.x} {max.yz, link, n}
+                    const float4* rec4 = reinterpret_cast<const float4*>(sc.nodes_aos) + (static_cast<size_t>(node) * 8 + static_cast<size_t>(cj)) * 2;
+                    const float4 c0 = rec4[0], c1 = rec4[1];  // {min.xyz, max.x} {max.yz, link, n}
                     const float bmn[3] = {c0.x, c0.y, c0.z}, bmx[3] = {c0.w, c1.x, c1.y};
                     keep = as_u(c1.z) != MP_LINK_NULL && bounds_may_hit<OCT>(reinterpret_cast<const float*>(mcache), bmn, bmx);
                 }
                 todo = static_cast<uint32_t>(__ballot(keep)) & 0xFFu;
                 if ((threadIdx.x & 63u) == 0u) mcache[cslot] = (node << 8) | todo;
             }
-            // children ascending (:161): popped descending.  The entry's mask = the rays live for THIS node
-            const uint64_t nm = __ballot(lim >= 0.0f);
-            while (todo != 0u) {
-                const uint32_t c = static_cast<uint32_t>(__builtin_ctz(todo));
-                todo &= todo - 1u;
-                st.push(sp, node * 8u + c, nm);
-                sp++;
+            if (todo != 0u) {  // a new frame; the one it replaces goes to the arrays if it still has children
+                if ((cur & 0xFFu) != 0u) {
+                    st.push(sp, cur, pm);
+                    sp++;
+                }
+                cur = (node << 8) | todo;
+                pm = __ballot(lim >= 0.0f);
             }
         } else {
             // intersect_triangles :104-140 ; every lane walks the leaf's surviving triangles in (packet, lane) order with a strict `<`
