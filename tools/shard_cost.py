@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How even are the N-GPU tile shards?  Renders the metric's frame once on one GPU, reads the per-tile shader-cycle counters
 (mp_launch_extras.tile_cost) and prints max / mean of the per-rank cost sums for the static r::N partition and for the
-longest-processing-time partition of bench.py --balance lpt, N = 2, 4, 8.  usage: shard_cost.py [spp] [depth]"""
+longest-processing-time partition of bench.py --balance lpt, N = 2, 4, 8.  usage: shard_cost.py [spp] [depth] [packet_samples_in_flight]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,6 +12,8 @@ from minipath_amd import scenes
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ctx = mp.Context(0)
+if len(sys.argv) > 3:
+    ctx.set_option("packet_samples_in_flight", int(sys.argv[3]))
 scene = mp.Scene(mp.TriangleBvh.build(*scenes.atrium(1, 1.0), ctx))
 st = mp.RenderSettings(64, spp, (1920, 1080), seed=0x5EED, max_depth=depth)
 fr = mp.FrameRenderer(scene, scenes.atrium_camera(), st)
@@ -39,4 +41,4 @@ full = timed(fr)
 tiles = list(fr.tiles)
 for n in (2, 4, 8):
     ms = [timed(mp.FrameRenderer(scene, scenes.atrium_camera(), st, tiles=tiles[r::n])) for r in range(n)]
-    print(f"N={n}: full frame {full:.2f} ms, ideal {full / n:.2f} ms, slowest static shard {max(ms):.2f} ms -> {full / max(ms):.2f}x before the gather")
+    print(f"N={n}: full frame {full:.2f} ms, ideal {full / n:.2f} ms, slowest static shard {max(ms):.2f} ms (mean {sum(ms) / n:.2f}) -> {full / max(ms):.2f}x before the gather")
