@@ -831,6 +831,12 @@ __device__ __forceinline__ kfp tri_record(kfp tp, uint32_t i) {
     return reinterpret_cast<kfp>(reinterpret_cast<const __attribute__((address_space(4))) char*>(tp) + scalar_u(i * static_cast<uint32_t>(kTriDwords * 4)));
 }
 
+#ifdef MP_PROF_MISSES  // profiling builds only (tools/build_variant.sh): slow-path calls of the mask cache, read by mp_prof_read
+__device__ unsigned long long g_prof[4];
+#define MP_PROF_COUNT(i) do { if ((threadIdx.x & 63u) == 0u) atomicAdd(&g_prof[i], 1ull); } while (0)
+#else
+#define MP_PROF_COUNT(i) do { } while (0)
+#endif
 // ---- packet-level child rejection with a per-unit mask cache (round 3) ----------------------------------------------------------
 // Counted on the metric's frame (tools/sim_collapse.py --packet-studies; profiles/r03_notes.md): a 64-ray camera packet tests 110
 // child boxes per pass and pushes 19; for 90 of the 91 others NO ray of the packet can pass, and a conservative test on bounds of
@@ -854,9 +860,17 @@ __device__ __forceinline__ kfp tri_record(kfp tp, uint32_t i) {
 #ifndef MP_MCACHE_PAD
 #define MP_MCACHE_PAD 0.25f  // widening of the unit's bounds on either side, in extents of the pass that sets them (A/B: 0.0625 .. 1, profiles/r03_notes.md)
 #endif
-constexpr int kMaskCacheEntries = 512;                      // direct-mapped: node index & 511 ; entry = node << 8 | mask
+// Table sizes (powers of two).  Counted on the metric's frame (tools/cache_miss_count.py, 16 passes per unit): 17.4 node-mask and 6.1
+// leaf-mask slow paths per unit, 1.08 bounds (re)sets; 256 / 256 entries: 22.8 and 5.1 (20.05 against 20.14 ms), 256 / 128: 20.23 ms.
+#ifndef MP_NODE_ENTRIES
+#define MP_NODE_ENTRIES 512
+#endif
+#ifndef MP_LEAF_ENTRIES
+#define MP_LEAF_ENTRIES 128
+#endif
+constexpr int kMaskCacheEntries = MP_NODE_ENTRIES;                      // direct-mapped: node index & 511 ; entry = node << 8 | mask
 constexpr int kMaskCacheHeader = 32;                        // B: [0..11] origin / inverse-direction bounds, [12] = sign pattern | 0x100 when valid (0xFFFFFFFF: none), [16..21] direction bounds
-constexpr int kLeafCacheEntries = 128;                      // direct-mapped: first packet of the leaf & 127 ; tag = first packet, mask = 64 bits (triangle i of the leaf)
+constexpr int kLeafCacheEntries = MP_LEAF_ENTRIES;                      // direct-mapped: first packet of the leaf & 127 ; tag = first packet, mask = 64 bits (triangle i of the leaf)
 constexpr int kLeafTagBase = kMaskCacheHeader + kMaskCacheEntries;
 constexpr int kLeafMaskBase = kLeafTagBase + kLeafCacheEntries;   // uint2 per entry (8-byte aligned)
 constexpr int kMaskCacheDwords = kLeafMaskBase + 2 * kLeafCacheEntries;
@@ -942,6 +956,7 @@ __device__ __forceinline__ bool mask_cache_begin_pass(const MaskCache& mc, const
                 pmin[g][k] = wlo; pmax[g][k] = whi;
             }
         }
+        MP_PROF_COUNT(3);
         wave_lds_sync();  // the reads above before the header is rewritten
         if (lane == 63) {
 #pragma unroll
@@ -1269,6 +1284,7 @@ __device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ra
         const uint32_t link = uniform_u(rec[6]);
         float lim = ok ? best_t : -1.0f;  // best.t for the rays this child is live for, -1 for the others: no slab interval and no hit distance passes
         if ((link & 63u) == 0u) {  // inner node (device link, mp_internal.h)
+            MP_PROF_COUNT(2);
             const uint32_t node = link >> 6;
             const uint32_t cslot = static_cast<uint32_t>(kMaskCacheHeader) + (node & static_cast<uint32_t>(kMaskCacheEntries - 1));
             const uint32_t e = __builtin_amdgcn_readfirstlane(mcache[cslot]);
@@ -1276,6 +1292,7 @@ __device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ra
             if (__builtin_expect((e >> 8) == node, 1)) {
                 todo = e & 0xFFu;
             } else {  // first visit of this node under the current bounds: lane j = child j, records through one vector load pair
+                MP_PROF_COUNT(0);
                 const int cj = static_cast<int>(threadIdx.x) & 7;
                 bool keep = false;
                 if ((threadIdx.x & 63u) < 8u) {
@@ -1333,6 +1350,7 @@ __device__ __forceinline__ void trace_packet_cached(const DevScene& sc, const Ra
             if (__builtin_expect(__builtin_amdgcn_readfirstlane(tag) == first, 1)) {
                 todo = __builtin_amdgcn_readfirstlane(tm.x) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(tm.y)) << 32);
             } else {  // first visit of this leaf under the current bounds
+                MP_PROF_COUNT(1);
                 const uint64_t m = leaf_mask_slow(sc.tris_aos, mcache, first, n_real);  // (a call's result is not known to be uniform)
                 todo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(m)) | (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(m >> 32))) << 32);
             }
@@ -3068,3 +3086,11 @@ int launch_quantise(const float* d_rgba_f32, uint8_t* d_rgba_u8, uint64_t n_pixe
 }
 
 }  // namespace mp
+
+#ifdef MP_PROF_MISSES
+extern "C" int mp_prof_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mp::g_prof), sizeof(unsigned long long) * 4) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mp::g_prof), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
