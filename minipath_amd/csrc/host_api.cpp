@@ -1368,6 +1368,7 @@ struct mp_render {
     std::chrono::nanoseconds elapsed{0};
     std::vector<std::thread> workers;
     std::atomic<int> live_workers{0};
+    size_t worker_count = 1;                     // contexts / worker threads of this render
     std::mutex status_mu;
     int status = MP_OK;                          // first error of any worker
     std::string error;
@@ -1434,13 +1435,21 @@ void render_worker(mp_render* r, size_t wi) {
     int cur = 0;
     while (my_status == MP_OK) {
         // get_next_tile (machinery.rs:205-208): abort() stores `len` so no new tiles are handed out
-        size_t first = r->next_tile.fetch_add(batch, std::memory_order_acq_rel);
+        // Batches taper towards the end of the frame (guided self-scheduling): the last batch's readback and filing are not
+        // overlapped by rendering, so the last ones are small -- a quarter of what is left per slot and worker, at least four tiles.
+        size_t first = r->next_tile.load(std::memory_order_acquire), take = 0;
+        for (;;) {
+            if (first >= total) break;
+            const size_t left = total - first;
+            take = std::min(left, std::max<size_t>(std::min<size_t>(batch, 4), std::min(batch, left / (4 * static_cast<size_t>(kSlots) * r->worker_count))));
+            if (r->next_tile.compare_exchange_weak(first, first + take, std::memory_order_acq_rel, std::memory_order_acquire)) break;
+        }
         if (first >= total) break;
         Slot& s = slot[cur];
         retire(s);  // the batch issued kSlots rounds ago
         if (my_status != MP_OK) break;
         s.first = first;
-        s.n = std::min(batch, total - first);
+        s.n = take;
         const mp_block* t = &r->tiles[first];
         if (r->started)
             for (size_t i = 0; i < s.n; i++) r->started(r->user, t[i]);  // machinery.rs:75
@@ -1521,6 +1530,7 @@ int mp_render_begin_multi(mp_ctx* const* ctxs, const mp_scene* const* scenes, in
     r->batch = batch;
     r->start = std::chrono::steady_clock::now();
     r->live_workers.store(n);
+    r->worker_count = static_cast<size_t>(n);
     try {
         for (int i = 0; i < n; i++) r->workers.emplace_back(render_worker, r.get(), static_cast<size_t>(i));
     } catch (const std::exception& ex) {
