@@ -844,9 +844,10 @@ __device__ unsigned long long g_prof[4];
 // (lane j = child j, the records through a vector load) was built first and ran slower than it saved (profiles/r03_notes.md).
 // What pays is doing it ONCE PER WORK UNIT: a unit shoots 8-16 passes through the same 2-4 pixels, and one set of bounds B that
 // contains every pass's rays gives one 8-bit "children that may be hit" mask per node, cached in LDS (the packet kernel uses no
-// other LDS).  A pass computes its own bounds P (12 wave reductions), and while P lies inside B and the sign pattern is the
-// same, a node visit costs one LDS lookup and the exact per-ray slab tests of the surviving children only.  B starts as the first
-// pass's P widened by half its extent; a pass that does not fit widens B and clears the cache.
+// other LDS).  Every pass checks, lane by lane, that its ray lies inside B (no reduction), and while that holds and the sign
+// pattern is the same, a node visit costs one LDS lookup and the exact per-ray slab tests of the surviving children only.  B starts
+// as the bounds of the first pass (wave reductions) widened by MP_MCACHE_PAD of their extent; a pass that does not fit widens B and
+// clears the cache.
 // Why skipping a child whose bit is clear is exact.  Only in the sign-specialised walks (OCT >= 0: every active ray has finite
 // inverse directions of one sign pattern) and only if every active origin and inverse component is finite.  Axis with inv > 0
 // (aabb.rs:257-271 gives lo = fl(fl(bmin - o) * inv), hi = fl(fl(bmax - o) * inv)): with omax >= o for every ray,
@@ -932,7 +933,7 @@ __device__ __forceinline__ bool mask_cache_begin_pass(const MaskCache& mc, const
             }
             wave_min3_max3(pmin[g], pmax[g]);
         }
-        // new bounds: this pass's, united with the old ones when they belong to the same sign pattern, widened by half the extent
+        // new bounds: this pass's, united with the old ones when they belong to the same sign pattern, widened by MP_MCACHE_PAD of the extent
         // (an inverse-direction bound never crosses zero: the sign pattern is part of the node masks' meaning; origin bounds stay
         // within 2^31 and direction bounds within 2: every pass that gets here lies well inside)
 #pragma unroll
