@@ -116,6 +116,11 @@ typedef struct {
  * MP_FLAG_ACCUMULATE passes gives the same bits (the tile buffer then carries {f32 chunk sum, f64 total (2 floats), hit count}
  * per pixel between launches).  Defined the same way in oracle/minipath_oracle.c (mpo_set_chunked_sum). */
 #define MP_FLAG_CHUNKED_SUM 32u
+/* render() only (mp_render_begin / mp_render_begin_multi): keep just the reference's image -- the u8 RgbaImage of machinery.rs:34 --
+ * on the host.  Without the flag the library also reads back and files the pre-quantisation f32 means (mp_render_image_f32, a
+ * build-defined extra: 16 bytes per pixel over PCIe and through the filing thread); with it mp_render_image_f32 is
+ * MP_ERR_UNSUPPORTED.  The u8 image is the same either way. */
+#define MP_FLAG_IMAGE_U8_ONLY 64u
 
 /* machinery.rs:180-189 RenderProgressSnapshot */
 typedef struct { size_t finished, total; } mp_progress;
@@ -263,9 +268,9 @@ int mp_scene_sphere(mp_ctx *ctx, const float center[3], float radius, mp_scene *
  * material; mp_scene_set_materials replaces it) and the first member's sky radiance.  get_bounding_box = union of the members'
  * boxes in the world frame (rotated member: the box of its box's rotated corners); mp_scene_info counts are sums over the
  * members.  The group SHARES its members' device arrays and holds a reference on each member: mp_scene_destroy on a member only
- * drops the caller's handle, the arrays are freed when the last group using them is destroyed too.  Rendered by the 8-lane-group traversal (every
- * kernel but the staged MP_FLAG_WAVEFRONT pipeline); defined operation by operation in oracle/minipath_oracle.c
- * (bvh_intersect_impl). */
+ * drops the caller's handle, the arrays are freed when the last group using them is destroyed too.  Rendered by every kernel: camera rays
+ * walk each TriangleBvh member as a 64-ray packet, bounce rays on the 8-lane-group traversal, and the staged MP_FLAG_WAVEFRONT
+ * pipeline takes groups too; defined operation by operation in oracle/minipath_oracle.c (bvh_intersect_impl). */
 int mp_scene_group(mp_ctx *ctx, const mp_scene *const *objects, const float *rotations, const float *translations, uint32_t n,
                    mp_scene **out);
 /* n members that are all `object` (instancing): as mp_scene_group, except that mp_scene_info reports the object's own counts and

@@ -21,6 +21,7 @@ MP_FLAG_PATHS = 4
 MP_FLAG_ACCUMULATE = 8
 MP_FLAG_WAVEFRONT = 16
 MP_FLAG_CHUNKED_SUM = 32
+MP_FLAG_IMAGE_U8_ONLY = 64
 
 
 MAX_MATERIALS = 65536  # MP_MAX_MATERIALS (include/minipath_hip.h)

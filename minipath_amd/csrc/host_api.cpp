@@ -1360,8 +1360,12 @@ struct mp_render {
     std::atomic<size_t> done_tiles{0};
     std::atomic<bool> finished_flag{false};
     std::mutex image_mu;                        // Mutex<RgbaImage> (machinery.rs:39)
-    std::vector<uint8_t> image_u8;
-    std::vector<float> image_f32;
+    // the host images: calloc'ed (zero pages come from the OS on first touch, i.e. when a worker files a tile -- not as a 40-MB fill
+    // before the first launch), sizes in elements
+    struct FreeDeleter { void operator()(void* p) const { std::free(p); } };
+    std::unique_ptr<uint8_t, FreeDeleter> image_u8;
+    std::unique_ptr<float, FreeDeleter> image_f32;
+    size_t image_elems = 0;   // width * height * 4
     std::chrono::steady_clock::time_point start;
     std::mutex end_mu;
     bool ended = false;
@@ -1424,8 +1428,8 @@ void render_worker(mp_render* r, size_t wi) {
                 for (uint32_t y = b.min_y; y < b.max_y; y++) {
                     const size_t src = i * per_tile + static_cast<size_t>(y - b.min_y) * ts * 4;
                     const size_t dst = (static_cast<size_t>(y) * st.width + b.min_x) * 4;
-                    std::memcpy(&r->image_f32[dst], s.h_f32 + src, w * 16);
-                    std::memcpy(&r->image_u8[dst], s.h_u8 + src, w * 4);
+                    if (r->image_f32) std::memcpy(r->image_f32.get() + dst, s.h_f32 + src, w * 16);
+                    std::memcpy(r->image_u8.get() + dst, s.h_u8 + src, w * 4);
                 }
             }
             size_t done = r->done_tiles.fetch_add(1, std::memory_order_acq_rel) + 1;
@@ -1462,7 +1466,7 @@ void render_worker(mp_render* r, size_t wi) {
             if (rc) fail(rc, err);
         }
         if (rc) { set_error(rc, mp_last_error()); break; }
-        e = hipMemcpyAsync(s.h_f32, s.d_f32, s.n * per_tile * 4, hipMemcpyDeviceToHost, s.stream);
+        e = r->image_f32 ? hipMemcpyAsync(s.h_f32, s.d_f32, s.n * per_tile * 4, hipMemcpyDeviceToHost, s.stream) : hipSuccess;
         if (e == hipSuccess) e = hipMemcpyAsync(s.h_u8, s.d_u8, s.n * per_tile, hipMemcpyDeviceToHost, s.stream);
         if (e != hipSuccess) { set_error(MP_ERR_HIP, std::string("tile readback: ") + hipGetErrorString(e)); break; }
         s.busy = true;
@@ -1516,8 +1520,11 @@ int mp_render_begin_multi(mp_ctx* const* ctxs, const mp_scene* const* scenes, in
     if (settings->flags & MP_FLAG_SHUFFLE_TILES)
         shuffle = static_cast<uint64_t>(std::chrono::steady_clock::now().time_since_epoch().count()) | 1ull;
     r->tiles = tile_ordering(mp_block{0, 0, settings->width, settings->height}, settings->tile_size, shuffle);
-    r->image_u8.assign(static_cast<size_t>(settings->width) * settings->height * 4, 0);   // RgbaImage::new :34
-    r->image_f32.assign(static_cast<size_t>(settings->width) * settings->height * 4, 0.0f);
+    r->image_elems = static_cast<size_t>(settings->width) * settings->height * 4;
+    r->image_u8.reset(static_cast<uint8_t*>(std::calloc(std::max<size_t>(r->image_elems, 1), 1)));   // RgbaImage::new :34 (zeroed)
+    const bool want_f32 = !(settings->flags & MP_FLAG_IMAGE_U8_ONLY);
+    if (want_f32) r->image_f32.reset(static_cast<float*>(std::calloc(std::max<size_t>(r->image_elems, 1), sizeof(float))));
+    if (!r->image_u8 || (want_f32 && !r->image_f32)) return fail(MP_ERR_NOMEM, "host image allocation failed");
     // A batch is what one launch renders: enough work units to fill every CU a few times over, small enough that the tile
     // callbacks keep flowing and that several devices share the queue evenly (the reference hands out one tile per worker).
     const uint32_t ts = settings->tile_size;
@@ -1594,7 +1601,7 @@ int mp_render_image_u8(mp_render* r, uint8_t* dst) {
     return guarded([&]() -> int {
     if (!r || !dst) return fail(MP_ERR_INVALID, "NULL argument");
     std::lock_guard<std::mutex> lk(r->image_mu);
-    std::memcpy(dst, r->image_u8.data(), r->image_u8.size());
+    std::memcpy(dst, r->image_u8.get(), r->image_elems);
     return MP_OK;
     });
 }
@@ -1602,8 +1609,9 @@ int mp_render_image_u8(mp_render* r, uint8_t* dst) {
 int mp_render_image_f32(mp_render* r, float* dst) {
     return guarded([&]() -> int {
     if (!r || !dst) return fail(MP_ERR_INVALID, "NULL argument");
+    if (!r->image_f32) return fail(MP_ERR_UNSUPPORTED, "this render keeps the u8 image only (MP_FLAG_IMAGE_U8_ONLY)");
     std::lock_guard<std::mutex> lk(r->image_mu);
-    std::memcpy(dst, r->image_f32.data(), r->image_f32.size() * 4);
+    std::memcpy(dst, r->image_f32.get(), r->image_elems * 4);
     return MP_OK;
     });
 }

@@ -27,6 +27,7 @@ class RenderSettings:
     max_depth: int = 0  # 0: reference semantics (primary ray + |d.n|).  >= 1: build-defined path extension (MP_FLAG_PATHS)
     wavefront: bool = False  # with max_depth >= 1: staged evaluation, bounce rays sorted into packets (MP_FLAG_WAVEFRONT)
     chunked_sum: bool = False  # build-defined: f32 sums over 256-sample chunks, f64 total (MP_FLAG_CHUNKED_SUM; configs[4])
+    image_u8_only: bool = False  # render(): keep only the reference's u8 image on the host (MP_FLAG_IMAGE_U8_ONLY; image_f32() then raises)
 
     def as_struct(self) -> _lib.SettingsStruct:
         if self.tile_size <= 0 or self.sample_count <= 0:
@@ -40,7 +41,8 @@ class RenderSettings:
             | (_lib.MP_FLAG_TRAVERSAL_GROUPS if self.traversal == "groups" else 0)
             | (_lib.MP_FLAG_PATHS if self.max_depth > 0 else 0)
             | (_lib.MP_FLAG_WAVEFRONT if (self.wavefront and self.max_depth > 0) else 0)
-            | (_lib.MP_FLAG_CHUNKED_SUM if self.chunked_sum else 0),
+            | (_lib.MP_FLAG_CHUNKED_SUM if self.chunked_sum else 0)
+            | (_lib.MP_FLAG_IMAGE_U8_ONLY if self.image_u8_only else 0),
             int(self.max_depth),
             0,
             0,

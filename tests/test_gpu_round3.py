@@ -1,5 +1,7 @@
 """GPU parity tests (-m gpu) of the round-3 features, all through the C ABI, bit-exact: progressive passes over several devices
 (mp_render_pass_multi, mp_untile_preview), object groups that outlive their members' handles."""
+import os
+
 import numpy as np
 import pytest
 
@@ -357,3 +359,43 @@ def test_packet_triangle_masks(oracle):
             img, _ = fr.untile()
             torch.cuda.synchronize()
             assert np.array_equal(bits(img.cpu().numpy()), bits(of)), (scale, fnum, mode, int(np.sum(bits(img.cpu().numpy()) != bits(of))))
+
+
+def test_cpp_mirror_renders_the_same_frame():
+    """examples/render_teapot (C++ over include/minipath.hpp: Camera().look_at(..).f_number(..), Scene::with_obj, render(), wait(),
+    image()) renders the frame the Python mirror renders through the same C ABI: FNV-1a of the u8 image."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples")], check=True, capture_output=True)
+    r = subprocess.run([os.path.join(root, "examples", "render_teapot"), TEAPOT, "320", "200", "16", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    line = [l for l in r.stdout.splitlines() if l.startswith("image fnv1a ")]
+    assert line, r.stdout
+    c = mp.Context(0)
+    scene = mp.Scene(mp.TriangleBvh.with_obj(TEAPOT, c))
+    prog = mp.render(scene, mp.Camera.teapot_view(), mp.RenderSettings(64, 16, (320, 200), seed=SEED))
+    prog.wait()
+    u8 = prog.image()
+    h = 1469598103934665603
+    for b in np.ascontiguousarray(u8).tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert line[0].split()[-1] == f"{h:016x}"
+    assert "20 / 20 tiles" in r.stdout
+
+
+def test_render_u8_only_flag():
+    """MP_FLAG_IMAGE_U8_ONLY: render() keeps just the reference's u8 RgbaImage on the host -- the same bytes as without the flag --
+    and mp_render_image_f32 then says MP_ERR_UNSUPPORTED."""
+    c = mp.Context(0)
+    scene = mp.Scene(mp.TriangleBvh.with_obj(TEAPOT, c))
+    res = (200, 120)
+    full = mp.render(scene, mp.Camera.teapot_view(), mp.RenderSettings(32, 24, res, seed=SEED))
+    full.wait()
+    lean = mp.render(scene, mp.Camera.teapot_view(), mp.RenderSettings(32, 24, res, seed=SEED, image_u8_only=True))
+    lean.wait()
+    assert np.array_equal(full.image(), lean.image()) and full.image().any()
+    assert full.image_f32().shape == (res[1], res[0], 4)
+    with pytest.raises(mp.MinipathError) as e:
+        lean.image_f32()
+    assert e.value.code == 5

@@ -522,3 +522,22 @@ def test_oracle_group_is_the_members_traced_one_by_one():
     assert np.array_equal(prim, bp) and np.array_equal(which[hit], bw[hit])
     for a, b in ((t, bt), (u, bu), (v, bv)):
         assert np.array_equal(a[hit].view(np.uint32), b[hit].view(np.uint32))
+
+
+def test_cpp_mirror_example_builds_and_reports_errors():
+    """include/minipath.hpp (header-only C++ mirror of the reference's Rust API over the C ABI) + examples/render_teapot.cpp
+    (benches/render_teapot.rs in those terms) compile with g++ and link against libminipath_hip.so; without a GPU the context
+    cannot be created and the failure surfaces as minipath::Error -> exit status 1 with the library's message (no abort, no
+    exception across the ABI)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples")], check=True, capture_output=True)
+    exe = os.path.join(root, "examples", "render_teapot")
+    assert os.path.exists(exe)
+    import torch
+
+    if torch.cuda.is_available():
+        return  # the GPU suite runs it for real (test_cpp_mirror_renders_the_same_frame)
+    r = subprocess.run([exe, os.path.join(root, "tests", "golden", "teapot.obj"), "64", "64", "1", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and r.stderr.startswith("error "), (r.returncode, r.stdout, r.stderr)

@@ -27,13 +27,14 @@ t0 = time.perf_counter()
 for _ in range(3): fr.render(); fr.untile(reuse=True)
 torch.cuda.synchronize()
 print(f"{which}: bare launch + un-tile {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per frame")
-for it in range(6):
+for it in range(8):
     n = [0]
     t0 = time.perf_counter()
     cbs = (lambda b: None, lambda b, s: n.__setitem__(0, n[0] + 1)) if it < 3 else (None, None)
-    prog = mp.render_multi(scs, cam, st, *cbs) if nctx > 1 else mp.render(scs[0], cam, st, *cbs)
+    st_ = st if it < 6 else mp.RenderSettings(64, 256, (1920, 1080), seed=0x5EED, image_u8_only=True)   # the last two: the reference's u8 image only
+    prog = mp.render_multi(scs, cam, st_, *cbs) if nctx > 1 else mp.render(scs[0], cam, st_, *cbs)
     prog.wait()
     t1 = time.perf_counter()
     img = prog.image()
     t2 = time.perf_counter()
-    print(f"render() over {nctx} context(s): {(t1-t0)*1e3:.1f} ms wall, {n[0]} finished callbacks, image copy {(t2-t1)*1e3:.1f} ms, elapsed() {prog.elapsed()*1e3:.1f} ms")
+    print(f"render() over {nctx} context(s){' (u8 image only)' if it >= 6 else ''}: {(t1-t0)*1e3:.1f} ms wall, {n[0]} finished callbacks, image copy {(t2-t1)*1e3:.1f} ms, elapsed() {prog.elapsed()*1e3:.1f} ms")
