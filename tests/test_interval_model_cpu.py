@@ -69,3 +69,41 @@ def test_interval_rejection_of_child_boxes_is_conservative():
                 rejected += int(rej.sum()); passed += int(some.sum()); wrong += int((rej & some).sum())
     assert wrong == 0
     assert passed > 0 and rejected > 0
+
+
+def test_corner_evaluation_bounds_every_operation():
+    """The one lemma both masks rest on: an f32 operation that is monotone in each operand (fl(a*b), fl(a*b+c), fl(a-b), fl(1/x) away from
+    zero) takes its extremes over a box of operands at the box's corners -- so the same operation evaluated at the corners bounds its
+    result for every operand inside.  Random boxes (spanning zero, tiny, huge, degenerate) and random points inside them, through the
+    interval helpers of tools/sim_tri_reject.py."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sim_tri_reject as st
+    from sim_collapse import fma32
+
+    F = np.float32
+    rng = np.random.default_rng(17)
+    n = 20000
+
+    def boxes():
+        scale = F(10.0) ** rng.integers(-6, 7, n).astype(F)
+        c = (rng.standard_normal(n).astype(F) * scale).astype(F)
+        w = (np.abs(rng.standard_normal(n)).astype(F) * scale * F(10.0) ** rng.integers(-4, 1, n).astype(F)).astype(F)
+        w[rng.random(n) < 0.1] = 0  # degenerate boxes
+        lo, hi = (c - w).astype(F), (c + w).astype(F)
+        x = (lo + (hi - lo) * rng.random(n).astype(F)).astype(F)
+        return st.Iv(lo, hi), np.clip(x, lo, hi).astype(F)
+
+    (A, a), (B, b), (Z, z) = boxes(), boxes(), boxes()
+    m = st.mul(A, B)
+    p = (a * b).astype(F)
+    assert np.all((m.lo <= p) & (p <= m.hi))
+    f = st.fma(A, B, Z)
+    q = fma32(a, b, z)
+    assert np.all((f.lo <= q) & (q <= f.hi))
+    d = st.sub(A, B)
+    r = (a - b).astype(F)
+    assert np.all((d.lo <= r) & (r <= d.hi))
+    nz = (A.lo > 0) | (A.hi < 0)  # reciprocal: only on boxes that stay away from zero
+    with np.errstate(divide="ignore", over="ignore"):
+        inv_lo, inv_hi, ia = (F(1) / A.hi), (F(1) / A.lo), (F(1) / a)
+    assert nz.any() and np.all((inv_lo[nz] <= ia[nz]) & (ia[nz] <= inv_hi[nz]))
