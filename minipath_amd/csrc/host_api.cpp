@@ -1534,7 +1534,7 @@ int mp_render_begin_multi(mp_ctx* const* ctxs, const mp_scene* const* scenes, in
     size_t batch = std::max<size_t>(1, (static_cast<size_t>(ctxs[0]->cu_count) * 8 + units_per_tile - 1) / units_per_tile);
     if (n > 1) batch = std::max<size_t>(1, std::min(batch, r->tiles.size() / (static_cast<size_t>(n) * 4)));
     if (ctxs[0]->render_batch.load() != 0) batch = ctxs[0]->render_batch.load();
-    r->batch = batch;
+    r->batch = std::max<size_t>(1, std::min(batch, r->tiles.size()));  // (the slots' buffers are sized by it)
     r->start = std::chrono::steady_clock::now();
     r->live_workers.store(n);
     r->worker_count = static_cast<size_t>(n);
