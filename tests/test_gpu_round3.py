@@ -392,8 +392,11 @@ def test_render_u8_only_flag():
     res = (200, 120)
     full = mp.render(scene, mp.Camera.teapot_view(), mp.RenderSettings(32, 24, res, seed=SEED))
     full.wait()
+    c.set_option("render_batch_tiles", 5)  # ... and odd batches that taper towards the end of the frame: the same image
     lean = mp.render(scene, mp.Camera.teapot_view(), mp.RenderSettings(32, 24, res, seed=SEED, image_u8_only=True))
     lean.wait()
+    c.set_option("render_batch_tiles", 0)
+    assert lean.progress().finished == lean.progress().total == 28
     assert np.array_equal(full.image(), lean.image()) and full.image().any()
     assert full.image_f32().shape == (res[1], res[0], 4)
     with pytest.raises(mp.MinipathError) as e:
