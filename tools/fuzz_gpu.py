@@ -4,7 +4,7 @@ produce zero direction components), resolutions, tile sizes, sample counts, kern
 work-unit sizes, progressive splits, material tables (grey, coloured, checker-textured) and sky radiance, instanced objects and object groups of different meshes, the
 chunked accumulation rule.  Every
 frame must match the oracle bit for bit.  usage: fuzz_gpu.py [cases] [seed] [cached]   ("cached": only cases that run the packet
-walk's mask-cache kernel -- plain scenes, 64 to 256 samples, 16 / 32 samples in flight, lenses from f/0.7 to a pinhole)"""
+walk's mask-cache kernel -- plain scenes, 16 to 256 samples, 4 to 32 samples in flight, lenses from f/0.05 to a pinhole, some cameras far away)"""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -56,7 +56,9 @@ def run(cases, seed, ctx=None):
         smp = po.build_sampler(oc, w, h)
         mode = str(rng.choice(["packets", "groups", "paths", "staged"]))
         if CACHED:   # only cases that run the packet walk's mask-cache kernel: plain scenes, units of four and more passes
-            mode = "packets"; spp = int(rng.choice([64, 70, 130, 256])); fnum = float(rng.choice([0.7, 1.4, 4.8, 16.0, 1e9]))
+            mode = "packets"; spp = int(rng.choice([16, 24, 33, 64, 70, 130, 256])); fnum = float(rng.choice([0.05, 0.7, 1.4, 4.8, 16.0, 1e9]))
+            if rng.random() < 0.15:   # a far-away camera: long rays, small footprints
+                eye = eye * float(rng.choice([30.0, 1000.0])); oc = po.Camera(); po.lib().mpo_camera_default(C.byref(oc)); po.lib().mpo_camera_look_at(C.byref(oc), po.vec3(*eye), po.vec3(*at), po.vec3(*up))
             cam = mp.Camera.default().look_at(tuple(eye), tuple(at), tuple(up)).f_number(fnum); oc.f_number = fnum
             smp = po.build_sampler(oc, w, h)
         depth = int(rng.integers(1, 6)) if mode in ("paths", "staged") else 0
@@ -65,7 +67,7 @@ def run(cases, seed, ctx=None):
         ctx.set_option("packet_stack_registers", int(rng.choice([64, 64, 3, 9])))
         ctx.set_option("paths_pooled", int(rng.choice([0, 1, 2, 3, 3])))
         if CACHED:
-            s_opt = int(rng.choice([0, 16, 32])); ctx.set_option("packet_samples_in_flight", s_opt); ctx.set_option("packet_stack_registers", 64)
+            s_opt = int(rng.choice([0, 0, 4, 8, 16, 32])); ctx.set_option("packet_samples_in_flight", s_opt); ctx.set_option("packet_stack_registers", 64)
         ctx.set_option("packet_mask_cache", 1 if CACHED else int(rng.choice([0, 1, 2, 2])))   # the packet walk's per-unit child-rejection masks   # one pass per walk / pooled passes of the fused path kernel
         chunked = bool(rng.random() < 0.25)
         if chunked:
