@@ -348,7 +348,8 @@ __device__ __forceinline__ void trace_wave(const DevScene& sc, float* __restrict
 // ... and for the pooled path kernel's queue of QS > 64 slots in global memory (inverse directions in rows 6..8)
 template <int QS>
 __device__ __forceinline__ void trace_wave_pool(const DevScene& sc, float* __restrict__ q, uint2* __restrict__ stack_base, int nrays) {
-    const int lane = static_cast<int>(threadIdx.x) & 63;
+    int lane = static_cast<int>(threadIdx.x) & 63;
+    asm volatile("" : "+v"(lane));  // (re-derived per call: the twelve row addresses below are not worth registers -- or spill slots -- across the kernel)
     bool inf = false;
 #pragma unroll
     for (int k = 0; k < QS / 64; k++) {
