@@ -26,6 +26,10 @@ constexpr int kQueueFloats = 6 * 64;  // ox,oy,oz,dx,dy,dz (unit direction) x 64
 
 __device__ __forceinline__ float as_f(uint32_t u) { return __uint_as_float(u); }
 __device__ __forceinline__ uint32_t as_u(float f) { return __float_as_uint(f); }
+// set bits of a wave mask below this lane (v_mbcnt: no per-lane mask register to keep)
+__device__ __forceinline__ int rank_below(uint64_t m) {
+    return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u)));
+}
 
 // LDS traffic between lanes of ONE wavefront: DS operations of a wave execute in issue order, so only the
 // compiler has to be kept from reordering them.
@@ -467,7 +471,7 @@ struct GroupHit {
 // group, in order, closest wins with a strict `<` (the first member keeps ties).
 template <bool OBJ, bool BFE = false>
 __device__ __forceinline__ void trace_objects(const DevScene& sc, const Ray& r, bool act, float* __restrict__ q,
-                                              uint2* __restrict__ stack, uint64_t lanes_lt, GroupHit& h) {
+                                              uint2* __restrict__ stack, GroupHit& h) {
     h.t = FLT_MAX; h.u = h.v = 0.0f; h.prim = kNoPrim; h.inst = 0u;
     auto pass = [&](const DevScene& sk, const Ray& rk, uint32_t k) {
         if (OBJ && sk.kind == 1u) {  // a Sphere member (scene/primitives.rs:16-48): lane-parallel, no walk; prim 0
@@ -477,7 +481,7 @@ __device__ __forceinline__ void trace_objects(const DevScene& sc, const Ray& r, 
         }
         const bool queued = act && may_hit_scene(sk, rk);
         const uint64_t am = __ballot(queued);
-        const int n = __popcll(am), rank = __popcll(am & lanes_lt);
+        const int n = __popcll(am), rank = rank_below(am);
         if (queued) {
             q[0 * 64 + rank] = rk.ox; q[1 * 64 + rank] = rk.oy; q[2 * 64 + rank] = rk.oz;
             q[3 * 64 + rank] = rk.dx; q[4 * 64 + rank] = rk.dy; q[5 * 64 + rank] = rk.dz;
@@ -639,7 +643,6 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams) {
     const uint32_t ts = P0.tile_size;
     const uint32_t bx = (ts + BW - 1) / BW, by = (ts + BH - 1) / BH, upt = bx * by;
     const uint32_t total = P0.n_tiles * upt;
-    const uint64_t lanes_lt = (1ull << lane) - 1ull;
     const int pix = lane / S, sub = lane % S;
 
     uint32_t qstate = blockIdx.x % kWorkQueues;
@@ -678,7 +681,7 @@ __global__ __launch_bounds__(256) void render_tiles_kernel(RenderParams) {
             }
             // group walk (once per member of an object group): closest hit, then the shading of worker.rs:59-65
             GroupHit gh;
-            trace_objects<OBJ>(P.scene, r, act, q, stack, lanes_lt, gh);
+            trace_objects<OBJ>(P.scene, r, act, q, stack, gh);
             float c = 0.0f, h = 0.0f;
             if (gh.prim != kNoPrim) {
                 float nn[3];
@@ -1964,8 +1967,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_PATHS_WP
     constexpr int BH = 64 / S / BW;
     const int lane = static_cast<int>(threadIdx.x) & 63, wave = static_cast<int>(threadIdx.x) >> 6;
     const int pix = lane / S, sub = lane % S;
-    const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1));
-    const uint64_t lanes_lt = (1ull << lane) - 1ull;
     unsigned long long segs = 0;  // wave-uniform
     uint32_t qstate = blockIdx.x % kWorkQueues;
     for (;;) {
@@ -2037,7 +2038,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_PATHS_WP
                     } else {
                         // bounce rays: group walk (once per member of an object group)
                         GroupHit gh;
-                        trace_objects<OBJ>(W.scene, r, alive, q, stack, lanes_lt, gh);
+                        trace_objects<OBJ>(W.scene, r, alive, q, stack, gh);
                         h.t = gh.t; h.u = gh.u; h.v = gh.v; h.prim = gh.prim;
                         hinst = gh.inst;
                     }
@@ -2045,7 +2046,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_PATHS_WP
                 const RenderParams& V = params_view(KP);  // shade + bounce
                 if (alive) alive = path_vertex<OBJ, N>(V.scene, h, depth, max_depth, rng, r, L, thr, primary_hit, hinst);
             }
-            cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
+            {   // (the mask of this pixel's lanes is rebuilt from the lane id here: two registers less across the walks)
+                int l_ = lane;
+                asm volatile("" : "+v"(l_));
+                const uint64_t pixel_lanes = (S == 64 ? ~0ull : ((1ull << (S & 63)) - 1ull)) << (l_ & ~(S - 1));
+                cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
+            }
 #pragma unroll
             for (int c = 0; c < N; c++) add_samples_in_order<S>(acc[c], L[c], lane);
             const RenderParams& A = params_view(KP);  // accumulation
@@ -2089,8 +2095,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_POOL_WPE
     const int lane = static_cast<int>(threadIdx.x) & 63;
     const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) >> 6);  // uniform: the pool / stack pointers stay in SGPRs
     const int pix = lane / S, sub = lane % S;
-    const uint64_t pixel_lanes = ((1ull << S) - 1ull) << (lane & ~(S - 1));
-    const uint64_t lanes_lt = (1ull << lane) - 1ull;
     unsigned long long segs = 0;  // wave-uniform
     uint32_t qstate = blockIdx.x % kWorkQueues;
     float* q;        // ray queue: kPoolQueueRows rows x QN slots
@@ -2115,7 +2119,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_POOL_WPE
     auto push_ray = [&](const DevScene& sc, const Ray& r, bool alive, uint32_t& nq, uint32_t& flags) {
         const bool queued = alive && may_hit_scene(sc, r);
         const uint64_t am = __ballot(queued);
-        const uint32_t slot = nq + static_cast<uint32_t>(__popcll(am & lanes_lt));
+        const uint32_t slot = nq + static_cast<uint32_t>(rank_below(am));
         if (queued) {
             q[0 * QN + slot] = r.ox; q[1 * QN + slot] = r.oy; q[2 * QN + slot] = r.oz;
             q[3 * QN + slot] = r.dx; q[4 * QN + slot] = r.dy; q[5 * QN + slot] = r.dz;
@@ -2232,7 +2236,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MP_POOL_WPE
                 const uint32_t* p = park + j * 64 + lane;
                 const float L = as_f(p[8 * QN]);
                 const bool primary_hit = (p[10 * QN] & kPoolPrimary) != 0u;
-                cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
+                {
+                    int l_ = lane;
+                    asm volatile("" : "+v"(l_));
+                    const uint64_t pixel_lanes = ((1ull << S) - 1ull) << (l_ & ~(S - 1));
+                    cnt += static_cast<float>(__popcll(__ballot(primary_hit) & pixel_lanes));
+                }
                 add_samples_in_order<S>(acc, L, lane);
             }
             const RenderParams& A = params_view(KP);  // accumulation
@@ -2491,7 +2500,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         // compaction of the rays that can reach the object into the wave's queue + the 8-lane-group walk (once per member of an
         // object group, closest wins)
         GroupHit gh;
-        trace_objects<OBJ>(P.scene, r, act, q, stack, (1ull << lane) - 1ull, gh);
+        trace_objects<OBJ>(P.scene, r, act, q, stack, gh);
         if (act) {
             P.st.hit_t[p] = gh.t;
             P.st.hit_prim[p] = gh.prim;
@@ -2607,7 +2616,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             continue;
         }
         GroupHit gh;
-        trace_objects<OBJ, true>(P.scene, r0, act, q, stack, (1ull << lane) - 1ull, gh);
+        trace_objects<OBJ, true>(P.scene, r0, act, q, stack, gh);
         const float t = gh.t, u = gh.u, v = gh.v;
         const uint32_t prim = gh.prim, inst = gh.inst;
         if (act) {
