@@ -107,3 +107,47 @@ def test_corner_evaluation_bounds_every_operation():
     with np.errstate(divide="ignore", over="ignore"):
         inv_lo, inv_hi, ia = (F(1) / A.hi), (F(1) / A.lo), (F(1) / a)
     assert nz.any() and np.all((inv_lo[nz] <= ia[nz]) & (ia[nz] <= inv_hi[nz]))
+
+
+def test_interval_rejection_on_adversarial_triangles():
+    """The triangle masks' argument on inputs a camera never produces: triangle soups at scales from 1e-5 to 1e5 (needles, near-degenerate
+    and exactly degenerate triangles among them), ray bundles from inside, grazing along edges and planes, with zero direction
+    components; bounds = the bundle's own box and a wider one.  Never a rejected triangle that some ray of the bundle hits."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sim_tri_reject as st
+
+    F = np.float32
+    rng = np.random.default_rng(23)
+    rejected = hit = wrong = 0
+    for case in range(120):
+        scale = F(10.0) ** F(rng.integers(-5, 6))
+        m = 48
+        v0 = (rng.standard_normal((m, 3)) * scale).astype(F)
+        e1 = (rng.standard_normal((m, 3)) * scale * F(10.0) ** rng.integers(-3, 1, (m, 1))).astype(F)
+        e2 = (rng.standard_normal((m, 3)) * scale * F(10.0) ** rng.integers(-3, 1, (m, 1))).astype(F)
+        e2[:4] = e1[:4] * F(2)          # exactly degenerate (collinear edges)
+        e2[4:8] = 0                     # zero edge
+        # a bundle of 64 rays: origins near a point, directions near a direction -- or aimed along a triangle's edge / inside its plane
+        o0 = (rng.standard_normal(3) * scale * 3).astype(F)
+        kind = case % 4
+        if kind == 0:
+            d0 = rng.standard_normal(3)
+        elif kind == 1:
+            d0 = (v0[10] + F(0.5) * e1[10]) - o0      # at a point of an edge
+        elif kind == 2:
+            d0 = e1[11] + F(1e-3) * e2[11]            # inside a triangle's plane
+            o0 = (v0[11] - F(2) * d0).astype(F)
+        else:
+            d0 = np.array([1.0, 0.0, 0.0])            # axis-aligned: zero components
+        spread_o, spread_d = F(10.0) ** F(rng.integers(-4, 0)) * scale, F(10.0) ** F(rng.integers(-5, -1))
+        o = (o0[None, :] + rng.standard_normal((64, 3)) * spread_o).astype(F)
+        d = d0[None, :] + rng.standard_normal((64, 3)) * spread_d * (0.0 if (kind == 3 and case % 8 == 3) else 1.0)
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(F)
+        ok, _ = st.mt_valid(v0, e1, e2, o, d)
+        some = ok.any(axis=0)
+        for pad in (0.0, 0.25):
+            eo, ed = (o.max(0) - o.min(0)) * F(pad), (d.max(0) - d.min(0)) * F(pad)
+            rej = st.interval_reject(v0, e1, e2, (o.min(0) - eo).astype(F), (o.max(0) + eo).astype(F), (d.min(0) - ed).astype(F), (d.max(0) + ed).astype(F))
+            rejected += int(rej.sum()); hit += int(some.sum()); wrong += int((rej & some).sum())
+    assert wrong == 0
+    assert hit > 50 and rejected > 1000
